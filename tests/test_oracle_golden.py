@@ -1,0 +1,72 @@
+"""Pins the numpy oracle (oracle/sesrq_oracle.py) to the reference: every stage of every
+golden fixture (produced by running the reference itself, tests/golden/make_golden.py) must
+be reproduced bit-for-bit."""
+import hashlib
+import os
+
+import numpy as np
+import pytest
+
+from conftest import golden_files, load_fixture, fixture_input, GOLDEN
+from oracle import sesrq_oracle as O
+
+STAGE_FILES = [f for f in golden_files() if not f.endswith((".params.npz", "tables.npz"))]
+
+
+def _sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+@pytest.mark.parametrize("path", STAGE_FILES, ids=[os.path.basename(p)[:-4] for p in STAGE_FILES])
+def test_forward_matches_reference_stage_by_stage(path):
+    fx, meta = load_fixture(path)
+    net = O.net_from_fixture(fx)
+    x = fixture_input(fx, meta)
+    st = O.forward(net, x, keep=True)
+    inv = {"out": "y"}
+    for name, want_sha in meta["sha"].items():
+        got = st[inv.get(name, name)]
+        if name.startswith("input") and name != "input4_special":
+            got = got.astype(np.int8)
+        assert _sha(got) == want_sha, f"{name} differs from the reference"
+    # stored arrays (crops keep everything) compared element-wise too, for readable failures
+    for name in fx.files:
+        if name in ("meta", "x") or name.startswith(("Wq", "add_const")):
+            continue
+        got = st[inv.get(name, name)]
+        np.testing.assert_array_equal(np.asarray(got).astype(fx[name].dtype), fx[name], err_msg=name)
+    assert list(st["y"].shape) == meta["out_shape"]
+
+
+def test_qconst_table():
+    t = np.load(os.path.join(GOLDEN, "tables.npz"))
+    for r, M, n in zip(t["r"], t["M"], t["n"]):
+        assert O.qconst(float(r)) == (int(M), int(n)), r
+
+
+def test_weight_quantiser_table():
+    t = np.load(os.path.join(GOLDEN, "tables.npz"))
+    for w, q, s in zip(t["wq_in"], t["wq_out"], t["wq_scale"]):
+        gq, gs = O.quantize_weight(w)
+        assert gs == float(s)
+        np.testing.assert_array_equal(gq, q)
+
+
+PARAM_FILES = golden_files("*.params.npz")
+
+
+@pytest.mark.parametrize("path", PARAM_FILES, ids=[os.path.basename(p)[:-11] for p in PARAM_FILES])
+def test_parameter_derivation(path):
+    """float collapsed convs + calibration (min,max) -> the integer bundle the reference wrote."""
+    p, pm = load_fixture(path)
+    fx, meta = load_fixture(path.replace(".params.npz", ".crop.npz"))
+    sz = [O.calib_scale_zero(0.0 if i == 5 else pm["min"][i], pm["max"][i]) for i in range(6)]
+    assert [s for s, _ in sz] == pm["scale"] == meta["scale"]
+    assert [z for _, z in sz] == pm["zero"] == meta["zero"]
+    ps = {5: 4, 6: 2, 3: 1}[pm["mflag"]]
+    net = O.derive_net([p[f"Wf{k}"] for k in range(5)], [p[f"bf{k}"] for k in range(5)], pm["scale"], pm["zero"], ps)
+    for k in range(5):
+        np.testing.assert_array_equal(net.layers[k].wq, fx[f"Wq{k}"], err_msg=f"Wq{k}")
+        np.testing.assert_array_equal(net.layers[k].add_const, fx[f"add_const{k}"], err_msg=f"add_const{k}")
+        assert (net.layers[k].M, net.layers[k].n) == (meta["M"][k], meta["n"][k])
+    assert (net.M_res, net.n_res) == (meta["M_res"], meta["n_res"])
