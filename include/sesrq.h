@@ -1,0 +1,131 @@
+/*
+ * sesrq -- MI355X-native INT8 SESR / NRDM integer inference (C ABI).
+ *
+ * Drop-in boundary for ONE hot path of gui-yupeng/sesr-pytorch-quantize: the per-conv chain
+ *   quantize_asymmetrical_by_tensor -> reshape_input_for_hardware_pe -> nn.Conv2d ->
+ *   PEs_and_bias_adder -> requan_conv2d_output -> ReLU  (x5)  -> PixelShuffle
+ * that the reference's sim.py executes as a torch.fx graph (sim.py:82-114, :205).  The
+ * reference has no FFI: its boundary is five Python callables that hand state to each other
+ * through files under ./output_pt/.  Each entry point below names the reference code it
+ * replaces (paths relative to the reference root).
+ *
+ * Plain C types only: pointers, sizes, ints.  Device pointers are HIP device pointers of
+ * the current device; `stream` is a hipStream_t passed as void* (NULL = default stream).
+ * All functions return 0 on success, non-zero on error; sesrq_last_error() returns a
+ * thread-local message for the last failure on the calling thread.
+ */
+#ifndef SESRQ_H
+#define SESRQ_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SESRQ_VERSION 1
+#define SESRQ_MAX_LAYERS 16
+#define SESRQ_MAX_CH 16
+
+/* data types of the frame buffers handed over the boundary (always NCHW, like the reference) */
+enum { SESRQ_F32 = 0, SESRQ_I8 = 1 };
+
+/* kernel families (sesrq_set_option(net, SESRQ_OPT_ENGINE, ...)) */
+enum { SESRQ_ENGINE_AUTO = 0, SESRQ_ENGINE_DOT4 = 1, SESRQ_ENGINE_MFMA = 2 };
+enum { SESRQ_OPT_ENGINE = 1, SESRQ_OPT_FORCE_GENERAL = 2 };
+
+/* One collapsed convolution with its integer epilogue.
+ *   w         : conv.weight.K.pt   (myQL/quan_func.py:71,78)  [oc][ic][k][k] int8
+ *   add_const : conv.bias.quanK.pt (myQL/quan_func.py:481-489) clamp16(bq - zero*sum(W)), [oc]
+ *   M, n      : requan_K_K+1 / n_K_K+1 (myQL/quan_func.py:495-515,527-528) t = acc*M*2^-n
+ *   relu      : activation after the requant node (models/model_utils_pt.py:15-18) */
+typedef struct sesrq_layer_desc {
+    int32_t k;                 /* 3 or 5 (odd, stride 1, same padding) */
+    int32_t ic, oc;            /* 1..16 */
+    const int8_t *w;
+    const int32_t *add_const;
+    uint32_t M;                /* < 2^16  (define.py REQUAN_BIT)   */
+    uint32_t n;                /* <= 32   (define.py REQUAN_N_MAX) */
+    int32_t relu;
+} sesrq_layer_desc;
+
+/* A whole net ("parameter bundle"; replaces the CWD-relative output_pt/ tree).
+ * Roles follow myQL/quan_func.py:220-280,523-609 by position: layer 0 quantises the fp32
+ * frame and publishes the long-residual operand; layer L-2 requantises into domain 1 and its
+ * epilogue merges the residual (M_res, n_res; quan_func.py:249-270); layer L-1 requantises into
+ * the output domain zero[L]/scale_out and is followed by PixelShuffle(pixel_shuffle). */
+typedef struct sesrq_net_desc {
+    int32_t n_layers;                  /* L >= 3 */
+    const sesrq_layer_desc *layers;    /* [L] */
+    const int32_t *zero;               /* [L+1] input.K.zero.pt, K = 0..L (test.py:185-217) */
+    float scale_in;                    /* f32(input.0.scale) */
+    float scale_out;                   /* f32(input.L.scale) */
+    uint32_t M_res, n_res;             /* requan_res / n_res (quan_func.py:259-267) */
+    int32_t pixel_shuffle;             /* 1 (none), 2, 4      (models/sesr_sim.py:31) */
+    int32_t pe_num;                    /* define.py PE          (must be 4) */
+    int32_t pe_acc_bits;               /* define.py PE_ACC_BIT  (18) */
+    int32_t pe_add_bits;               /* define.py PE_ADD_BIT  (20) */
+} sesrq_net_desc;
+
+typedef struct sesrq_net sesrq_net;
+
+/* ---- device path ------------------------------------------------------------------ */
+
+/* Validates the bundle, repacks the weights for the kernels and uploads them to the current
+ * HIP device.  The net is immutable afterwards: forward calls are thread-safe and
+ * stream-ordered.  Replaces quantize_model_weight's file output + every torch.load of
+ * the output_pt/ tree inside the five callables. */
+int sesrq_create(const sesrq_net_desc *desc, sesrq_net **out);
+void sesrq_destroy(sesrq_net *net);
+int sesrq_set_option(sesrq_net *net, int option, int value);
+
+/* Bytes of device workspace sesrq_forward needs for N frames of H x W (caller-owned). */
+size_t sesrq_workspace_bytes(const sesrq_net *net, int N, int H, int W);
+
+/* The hot path: replaces `gfake = model(inps)` (sim.py:205).
+ *   in     : (N, Cin, H, W)  fp32 frame (SESRQ_F32)  or already-quantised q0 int8 (SESRQ_I8)
+ *   out_q  : (N, Cout, H*r, W*r) int8  -- input.L.pt after PixelShuffle; may be NULL
+ *   out_f  : same shape, fp32 (q - zero_L) * scale_out -- what the reference returns
+ *            (quan_func.py:594); may be NULL
+ * No allocation, no synchronisation; everything is enqueued on `stream`. */
+int sesrq_forward(const sesrq_net *net, const void *in, int in_dtype, void *out_q, void *out_f,
+                  int N, int H, int W, void *workspace, size_t workspace_bytes, void *stream);
+
+/* Debug taps mirroring the reference's dump flags (define.py:23-31).  After a forward run
+ * with sesrq_forward_debug, stage tensors are written to caller buffers (device pointers, any
+ * may be NULL):
+ *   act[k]    : (N, C_k, H, W) int8   input.k.pt, k = 0..L-1      (INPUT_W_FLG)
+ *   pe_out[k] : (N, 4, OC_k, H, W) int32 pe_outputK_P.pt           (OUTPUT_PE_W_FLG)
+ *   pe_add[k] : (N, OC_k, H, W) int32 pe_add_outputK.pt            (OUTPUT_PE_ADD_W_FLG) */
+typedef struct sesrq_taps {
+    void *act[SESRQ_MAX_LAYERS];
+    void *pe_out[SESRQ_MAX_LAYERS];
+    void *pe_add[SESRQ_MAX_LAYERS];
+} sesrq_taps;
+int sesrq_forward_debug(const sesrq_net *net, const void *in, int in_dtype, void *out_q, void *out_f,
+                        int N, int H, int W, void *workspace, size_t workspace_bytes, void *stream,
+                        const sesrq_taps *taps);
+
+/* Name of the kernel family the net resolved to for layer k ("dot4-general", "mfma-merged", ...). */
+const char *sesrq_layer_engine(const sesrq_net *net, int k);
+
+/* ---- host scalar code of the path (load time) -------------------------------------- */
+
+/* quan_layer_between_const (myQL/quan_func.py:495-515): r -> (M, n), truncating. */
+int sesrq_requant_const(double r, int data_bit, int shift_max, uint32_t *M, uint32_t *n);
+/* quantize_symmetrical_by_tensor (myQL/quan_func.py:58-71): per-tensor symmetric INT8. */
+int sesrq_quantize_weight(const float *w, size_t count, int width, int8_t *wq, double *scale);
+/* quantize_bias_with_scale + add-constant (myQL/quan_func.py:402,448-449,481-486). */
+int sesrq_add_const(const float *bias, const int8_t *wq, int oc, int per_oc, double s_in, int z_in,
+                    double s_w, int bias_width, int32_t *out);
+/* min/max -> scale/zero (test.py:185-217). */
+int sesrq_calib_scale_zero(double min_val, double max_val, int width, double *scale, int *zero);
+
+const char *sesrq_last_error(void);
+int sesrq_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SESRQ_H */

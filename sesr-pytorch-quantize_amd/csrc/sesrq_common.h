@@ -1,0 +1,73 @@
+// Internal declarations shared by the sesrq translation units (not part of the C ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+
+#include "sesrq.h"
+
+namespace sesrq {
+
+enum Epi { EPI_MID = 0, EPI_PRERES = 1, EPI_LAST = 2 };
+enum Src { SRC_NHWC16 = 0, SRC_F32 = 1, SRC_I8 = 2 };
+
+// Per-launch arguments of one conv layer.  Lives in the kernarg segment (SGPR loads).
+struct ConvArgs {
+    const void *in;          // SRC_NHWC16: uint4 per pixel ; SRC_F32/SRC_I8: NCHW planes
+    void *out;               // EPI_MID/PRERES: NHWC16 int8 ; EPI_LAST: unused
+    const void *rc_in;       // EPI_PRERES: NHWC16 residual operand rc = clamp8(rint(short-128))
+    void *rc_out;            // layer 0 only, when zero[1] != -128: separate rc tensor (else NULL)
+    void *out_q;             // EPI_LAST: (N, C, H*r, W*r) int8 or NULL
+    float *out_f;            // EPI_LAST: same shape fp32 or NULL
+    const int *wpk;          // packed weights [tap][OCP][4] dwords (see pack_weights)
+    int *dbg_pe;             // (N,4,OC,H,W) int32 or NULL
+    int *dbg_add;            // (N,OC,H,W) int32 or NULL
+    signed char *dbg_q0;     // (N,IC,H,W) int8: quantised input of layer 0 or NULL
+    int N, H, W;
+    int ic, oc;              // real channel counts
+    int pad_word;            // zc replicated into 4 bytes
+    int acc_lo, acc_hi, add_lo, add_hi;
+    float Mf, sh;            // (float)M, 2^-n
+    float z_next;            // (float) zero of the domain this layer requantises into (+zero add)
+    float Mres, shres;       // EPI_PRERES
+    float z_merge;           // EPI_PRERES: zero of the last conv's input domain
+    float s_in, z_in;        // SRC_F32: f32(scale_0), (float)zero_0
+    float s_out, z_out;      // EPI_LAST: f32(scale_L), (float) zero_L
+    int relu;
+    int ps;                  // EPI_LAST pixel shuffle factor
+    int add_const[SESRQ_MAX_CH];
+};
+
+struct LayerPlan {
+    int k, ic, oc, ocp;
+    bool general;            // per-PE accumulators + 18/20-bit clamps needed
+    std::string engine;
+    int *d_wpk_general = nullptr;   // device
+    int *d_wpk_merged = nullptr;    // device
+    ConvArgs base;           // constant fields prefilled
+    // static saturation analysis (per layer)
+    long long worst_pe = 0, worst_sum = 0;
+};
+
+void set_error(const std::string &msg);
+
+// dot4 engine
+int launch_dot4(const LayerPlan &lp, const ConvArgs &a, int src, int epi, hipStream_t st);
+int launch_unpack_nhwc16(const void *nhwc, signed char *nchw, int N, int C, int H, int W, hipStream_t st);
+
+}  // namespace sesrq
+
+struct sesrq_net {
+    int L = 0;
+    std::vector<sesrq::LayerPlan> layers;
+    std::vector<int> zero;
+    float scale_in = 0.f, scale_out = 0.f;
+    uint32_t M_res = 0, n_res = 0;
+    int ps = 1;
+    int acc_bits = 18, add_bits = 20;
+    int engine = SESRQ_ENGINE_AUTO;
+    int force_general = 0;
+    int device = 0;
+    bool rc_separate = false;   // zero[1] != -128 -> layer 0 writes its own rc tensor
+};

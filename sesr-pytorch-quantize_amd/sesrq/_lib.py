@@ -1,0 +1,85 @@
+"""ctypes binding of libsesrq.so (C ABI declared in include/sesrq.h).
+
+The library is the product: if it is missing or a symbol cannot be resolved this module
+raises immediately -- there is no CPU or PyTorch fallback anywhere in the package.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.normpath(os.path.join(_HERE, "..", "lib", "libsesrq.so"))
+
+MAX_LAYERS = 16
+MAX_CH = 16
+F32, I8 = 0, 1
+ENGINE_AUTO, ENGINE_DOT4, ENGINE_MFMA = 0, 1, 2
+OPT_ENGINE, OPT_FORCE_GENERAL = 1, 2
+
+
+class LayerDesc(C.Structure):
+    _fields_ = [("k", C.c_int32), ("ic", C.c_int32), ("oc", C.c_int32),
+                ("w", C.POINTER(C.c_int8)), ("add_const", C.POINTER(C.c_int32)),
+                ("M", C.c_uint32), ("n", C.c_uint32), ("relu", C.c_int32)]
+
+
+class NetDesc(C.Structure):
+    _fields_ = [("n_layers", C.c_int32), ("layers", C.POINTER(LayerDesc)), ("zero", C.POINTER(C.c_int32)),
+                ("scale_in", C.c_float), ("scale_out", C.c_float), ("M_res", C.c_uint32), ("n_res", C.c_uint32),
+                ("pixel_shuffle", C.c_int32), ("pe_num", C.c_int32), ("pe_acc_bits", C.c_int32),
+                ("pe_add_bits", C.c_int32)]
+
+
+class Taps(C.Structure):
+    _fields_ = [("act", C.c_void_p * MAX_LAYERS), ("pe_out", C.c_void_p * MAX_LAYERS),
+                ("pe_add", C.c_void_p * MAX_LAYERS)]
+
+
+# every symbol include/sesrq.h declares: name -> (restype, argtypes)
+SYMBOLS = {
+    "sesrq_create": (C.c_int, [C.POINTER(NetDesc), C.POINTER(C.c_void_p)]),
+    "sesrq_destroy": (None, [C.c_void_p]),
+    "sesrq_set_option": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
+    "sesrq_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_int, C.c_int, C.c_int]),
+    "sesrq_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                C.c_void_p, C.c_size_t, C.c_void_p]),
+    "sesrq_forward_debug": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
+                                      C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.POINTER(Taps)]),
+    "sesrq_layer_engine": (C.c_char_p, [C.c_void_p, C.c_int]),
+    "sesrq_requant_const": (C.c_int, [C.c_double, C.c_int, C.c_int, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
+    "sesrq_quantize_weight": (C.c_int, [C.POINTER(C.c_float), C.c_size_t, C.c_int, C.POINTER(C.c_int8),
+                                        C.POINTER(C.c_double)]),
+    "sesrq_add_const": (C.c_int, [C.POINTER(C.c_float), C.POINTER(C.c_int8), C.c_int, C.c_int, C.c_double, C.c_int,
+                                  C.c_double, C.c_int, C.POINTER(C.c_int32)]),
+    "sesrq_calib_scale_zero": (C.c_int, [C.c_double, C.c_double, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int)]),
+    "sesrq_last_error": (C.c_char_p, []),
+    "sesrq_version": (C.c_int, []),
+}
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    """Load libsesrq.so once and bind every declared symbol; raise loudly when it is absent."""
+    global _lib
+    if _lib is None:
+        if not os.path.isfile(LIB_PATH):
+            raise RuntimeError(
+                f"sesrq: native library not found at {LIB_PATH}. Build it with "
+                "`make -C sesr-pytorch-quantize_amd/csrc` (or __graft_entry__.build()); there is no fallback path.")
+        handle = C.CDLL(LIB_PATH)
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(handle, name)          # AttributeError if the .so lacks a declared symbol
+            fn.restype, fn.argtypes = res, args
+        _lib = handle
+    return _lib
+
+
+def last_error() -> str:
+    return (lib().sesrq_last_error() or b"").decode()
+
+
+def check(rc: int, exc=RuntimeError) -> None:
+    if rc != 0:
+        raise exc("sesrq: " + last_error())

@@ -1,0 +1,138 @@
+"""Device engine: a Bundle uploaded to one GPU (sesrq_create) + the fused integer forward
+(sesrq_forward).  torch is plumbing only: device memory, the current HIP stream."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, Optional
+
+import numpy as np
+import torch
+
+from . import _lib
+from .bundle import Bundle
+
+
+class Engine:
+    """One immutable net on one device.  forward() is stream-ordered and allocation-free once
+    the workspace for a given (N, H, W) exists."""
+
+    def __init__(self, bundle: Bundle, device: Optional[torch.device] = None, engine: int = _lib.ENGINE_AUTO,
+                 force_general: bool = False):
+        if not torch.cuda.is_available():
+            raise RuntimeError("sesrq.Engine needs a HIP device (torch.cuda.is_available() is False); "
+                               "there is no CPU fallback in this package")
+        self.bundle = bundle
+        self.device = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
+        L = bundle.L
+        self._keep = []
+        layers = (_lib.LayerDesc * L)()
+        for k, l in enumerate(bundle.layers):
+            w = np.ascontiguousarray(l.wq, dtype=np.int8)
+            ac = np.ascontiguousarray(l.add_const, dtype=np.int32)
+            self._keep += [w, ac]
+            layers[k] = _lib.LayerDesc(k=w.shape[2], ic=w.shape[1], oc=w.shape[0],
+                                       w=w.ctypes.data_as(C.POINTER(C.c_int8)),
+                                       add_const=ac.ctypes.data_as(C.POINTER(C.c_int32)),
+                                       M=l.M, n=l.n, relu=int(l.relu))
+        zero = (C.c_int32 * (L + 1))(*bundle.zero)
+        desc = _lib.NetDesc(n_layers=L, layers=layers, zero=zero,
+                            scale_in=float(np.float32(bundle.scale[0])), scale_out=float(np.float32(bundle.scale[L])),
+                            M_res=bundle.M_res, n_res=bundle.n_res, pixel_shuffle=bundle.pixel_shuffle,
+                            pe_num=bundle.pe_num, pe_acc_bits=bundle.pe_acc_bits, pe_add_bits=bundle.pe_add_bits)
+        handle = C.c_void_p()
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.lib().sesrq_create(C.byref(desc), C.byref(handle)), ValueError)
+        self._h = handle
+        if engine != _lib.ENGINE_AUTO:
+            _lib.check(_lib.lib().sesrq_set_option(self._h, _lib.OPT_ENGINE, engine), ValueError)
+        if force_general:
+            _lib.check(_lib.lib().sesrq_set_option(self._h, _lib.OPT_FORCE_GENERAL, 1), ValueError)
+        self._ws: Dict[tuple, torch.Tensor] = {}
+
+    def close(self):
+        if getattr(self, "_h", None):
+            _lib.lib().sesrq_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------
+    def layer_engines(self):
+        return [(_lib.lib().sesrq_layer_engine(self._h, k) or b"").decode() for k in range(self.bundle.L)]
+
+    def out_shape(self, N, H, W):
+        r = self.bundle.pixel_shuffle
+        return (N, self.bundle.out_channels, H * r, W * r)
+
+    def workspace(self, N, H, W) -> torch.Tensor:
+        key = (N, H, W)
+        ws = self._ws.get(key)
+        if ws is None:
+            nbytes = _lib.lib().sesrq_workspace_bytes(self._h, N, H, W)
+            ws = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+            self._ws[key] = ws
+        return ws
+
+    def _check_in(self, x: torch.Tensor):
+        if x.dim() != 4:
+            raise ValueError("Expect input tensor dimension: 4, but get %d" % x.dim())
+        if x.device != self.device:
+            raise ValueError(f"input is on {x.device}, engine on {self.device}")
+        if x.shape[1] != self.bundle.in_channels:
+            raise ValueError(f"expected {self.bundle.in_channels} input channels, got {x.shape[1]}")
+        if x.dtype == torch.float32:
+            return _lib.F32
+        if x.dtype == torch.int8:
+            return _lib.I8
+        raise ValueError("input must be float32 (frame) or int8 (already quantised q0)")
+
+    def forward(self, x: torch.Tensor, want_q: bool = True, want_f: bool = True, out_q=None, out_f=None):
+        """x: (N, Cin, H, W) float32 | int8 on self.device -> (q int8 | None, y float32 | None)."""
+        dt = self._check_in(x)
+        x = x.contiguous()
+        N, _, H, W = x.shape
+        shp = self.out_shape(N, H, W)
+        if want_q and out_q is None:
+            out_q = torch.empty(shp, dtype=torch.int8, device=self.device)
+        if want_f and out_f is None:
+            out_f = torch.empty(shp, dtype=torch.float32, device=self.device)
+        ws = self.workspace(N, H, W)
+        st = torch.cuda.current_stream(self.device).cuda_stream
+        rc = _lib.lib().sesrq_forward(self._h, x.data_ptr(), dt, out_q.data_ptr() if out_q is not None else None,
+                                      out_f.data_ptr() if out_f is not None else None, N, H, W, ws.data_ptr(),
+                                      ws.numel(), st)
+        _lib.check(rc)
+        return out_q, out_f
+
+    __call__ = forward
+
+    def forward_debug(self, x: torch.Tensor, pe: bool = True):
+        """Forward with the reference's dump taps (define.py *_W_FLG): returns a dict with
+        q_out, y, input{k} (int8 NCHW), pe_out{k} (N,4,OC,H,W int32), pe_add{k} (N,OC,H,W int32)."""
+        dt = self._check_in(x)
+        x = x.contiguous()
+        N, _, H, W = x.shape
+        L = self.bundle.L
+        shp = self.out_shape(N, H, W)
+        res = {"q_out": torch.empty(shp, dtype=torch.int8, device=self.device),
+               "y": torch.empty(shp, dtype=torch.float32, device=self.device)}
+        taps = _lib.Taps()
+        for k, l in enumerate(self.bundle.layers):
+            oc, ic = l.wq.shape[0], l.wq.shape[1]
+            res[f"input{k}"] = torch.empty((N, ic, H, W), dtype=torch.int8, device=self.device)
+            taps.act[k] = res[f"input{k}"].data_ptr()
+            if pe:
+                res[f"pe_out{k}"] = torch.empty((N, 4, oc, H, W), dtype=torch.int32, device=self.device)
+                res[f"pe_add{k}"] = torch.empty((N, oc, H, W), dtype=torch.int32, device=self.device)
+                taps.pe_out[k] = res[f"pe_out{k}"].data_ptr()
+                taps.pe_add[k] = res[f"pe_add{k}"].data_ptr()
+        ws = self.workspace(N, H, W)
+        st = torch.cuda.current_stream(self.device).cuda_stream
+        rc = _lib.lib().sesrq_forward_debug(self._h, x.data_ptr(), dt, res["q_out"].data_ptr(), res["y"].data_ptr(),
+                                            N, H, W, ws.data_ptr(), ws.numel(), st, C.byref(taps))
+        _lib.check(rc)
+        return res

@@ -1,0 +1,174 @@
+"""GPU parity tests proper (-m gpu): the HIP path, called through the C ABI, against
+(1) the golden vectors produced by the reference itself and (2) the pinned oracle on seeded
+inputs.  Bar: bit-exact on every int8/int32 tensor; the fp32 output is a deterministic
+function of the int8 tensor ((q - z) * f32(scale), one rounding) and must be bit-equal too."""
+import hashlib
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden_files
+from helpers import bundle_from_oracle, fixture_case, rand_frame
+from oracle import sesrq_oracle as O
+import sesrq
+from sesrq import _lib
+
+pytestmark = pytest.mark.gpu
+
+STAGE_FILES = [f for f in golden_files() if not f.endswith((".params.npz", "tables.npz"))]
+ENGINES = [("dot4", _lib.ENGINE_DOT4), ("mfma", _lib.ENGINE_MFMA)]
+
+
+def _sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def _dev():
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    return torch.device("cuda:0")
+
+
+def _cmp(name, got, want):
+    got = got.cpu().numpy() if isinstance(got, torch.Tensor) else got
+    if got.shape != want.shape:
+        raise AssertionError(f"{name}: shape {got.shape} != {want.shape}")
+    bad = np.argwhere(got != want)
+    if len(bad):
+        i = tuple(bad[0])
+        raise AssertionError(f"{name}: {len(bad)} mismatches, first at {i}: got {got[i]} want {want[i]}")
+
+
+@pytest.mark.parametrize("eng", ENGINES, ids=[e[0] for e in ENGINES])
+@pytest.mark.parametrize("path", STAGE_FILES, ids=[os.path.basename(p)[:-4] for p in STAGE_FILES])
+def test_golden_stage_by_stage(path, eng):
+    """Every tensor the reference dumped (input.K, pe_outputK_P, pe_add_outputK, final) on the
+    reference's own inputs, including the adversarial zero-point / saturating-weight runs."""
+    fx, meta, net, x = fixture_case(path)
+    e = sesrq.Engine(bundle_from_oracle(net), _dev(), engine=eng[1])
+    xt = torch.from_numpy(x).to(_dev())
+    res = e.forward_debug(xt)
+    r = net.pixel_shuffle
+    got = {k: v.cpu().numpy() for k, v in res.items()}
+    # un-shuffle q_out to compare with input5
+    N, C, Ho, Wo = got["q_out"].shape
+    q5 = got["q_out"].reshape(N, C, Ho // r, r, Wo // r, r).transpose(0, 1, 3, 5, 2, 4).reshape(N, C * r * r, Ho // r, Wo // r)
+    got["input5"] = q5
+    got["out"] = got["y"]
+    for k in range(5):
+        got[f"pe_out{k}"] = got[f"pe_out{k}"][0]
+    for name, want_sha in meta["sha"].items():
+        if name in ("shortcut", "input4_special"):
+            continue     # fp32 shortcut / its re-quantisation are internal to the fused epilogues
+        assert _sha(got[name]) == want_sha, f"{name} differs from the reference"
+    for name in fx.files:
+        if name in got and name not in ("x",):
+            _cmp(name, got[name], fx[name])
+    # production call (no taps) must give the same result as the debug call
+    q, y = e.forward(xt)
+    _cmp("q_out(production)", q, got["q_out"])
+    _cmp("y(production)", y, got["y"])
+
+
+SIZES = [(1, 1, 1), (1, 3, 5), (1, 8, 32), (1, 9, 33), (2, 17, 70), (1, 40, 129), (3, 31, 64)]
+
+
+@pytest.mark.parametrize("eng", ENGINES, ids=[e[0] for e in ENGINES])
+@pytest.mark.parametrize("kind", ["sesr_x4", "sesr_x2", "nrdm"])
+@pytest.mark.parametrize("hard", [False, True], ids=["plain", "hard"])
+def test_synthetic_nets_vs_oracle(kind, hard, eng):
+    """Seeded random bundles (plain: saturation-free -> merged kernels; hard: wide weights and odd
+    zero points -> general kernels with the 18/20-bit clamps firing), ragged sizes, batches."""
+    for seed in range(2):
+        net = O.synth_net(kind, seed, hard=hard)
+        e = sesrq.Engine(bundle_from_oracle(net), _dev(), engine=eng[1])
+        cin = net.layers[0].wq.shape[1]
+        for (N, H, W) in SIZES:
+            x = rand_frame((N, cin, H, W), 1000 * seed + H * W)
+            want = O.forward(net, x)
+            q, y = e.forward(torch.from_numpy(x).to(_dev()))
+            _cmp(f"{net.name} {N}x{H}x{W} q_out", q, want["q_out"])
+            _cmp(f"{net.name} {N}x{H}x{W} y", y, want["y"])
+
+
+@pytest.mark.parametrize("eng", ENGINES, ids=[e[0] for e in ENGINES])
+def test_general_and_merged_kernels_agree(eng):
+    """force_general runs the per-PE kernels on a saturation-free bundle: same bits."""
+    net = O.synth_net("sesr_x2", 5)
+    b = bundle_from_oracle(net)
+    x = torch.from_numpy(rand_frame((2, 3, 37, 91), 9)).to(_dev())
+    e0 = sesrq.Engine(b, _dev(), engine=eng[1])
+    e1 = sesrq.Engine(b, _dev(), engine=eng[1], force_general=True)
+    assert any("merged" in s for s in e0.layer_engines())
+    q0, y0 = e0.forward(x)
+    q1, y1 = e1.forward(x)
+    assert torch.equal(q0, q1) and torch.equal(y0, y1)
+    want = O.forward(net, x.cpu().numpy())
+    _cmp("q_out", q0, want["q_out"])
+
+
+def test_int8_input_path():
+    """The boundary also accepts an already-quantised q0 (input.0.pt) instead of the fp32 frame."""
+    net = O.synth_net("nrdm", 2, hard=True)
+    e = sesrq.Engine(bundle_from_oracle(net), _dev())
+    x = rand_frame((1, 3, 20, 45), 4)
+    q0 = O.quantize_input(x, net.scale[0], net.zero[0])
+    qa, _ = e.forward(torch.from_numpy(x).to(_dev()))
+    qb, _ = e.forward(torch.from_numpy(q0).to(_dev()))
+    assert torch.equal(qa, qb)
+
+
+def test_deeper_net_positional_roles():
+    """nrdm_6-shaped net (8 convs): roles generalised by position; parity UNPINNED w.r.t. the
+    reference (it cannot int-simulate this depth) -- oracle vs HIP self-consistency only."""
+    net = O.synth_net("nrdm", 11, n_blocks=6)
+    e = sesrq.Engine(bundle_from_oracle(net), _dev())
+    x = rand_frame((1, 3, 33, 47), 5)
+    want = O.forward(net, x)
+    q, y = e.forward(torch.from_numpy(x).to(_dev()))
+    _cmp("q_out", q, want["q_out"])
+    _cmp("y", y, want["y"])
+
+
+def test_full_size_properties_1080p():
+    """BASELINE config 2 size (1x3x1080x1920 -> 3x2160x3840): size-independent properties.
+    (a) translation consistency: a crop that keeps a 7-pixel halo reproduces the interior of the
+        full-frame result bit-for-bit (receptive field 2+1+1+1+2 = 7);
+    (b) batch independence: frames in a batch equal the same frames run alone;
+    (c) determinism: two runs give identical bytes."""
+    net = O.synth_net("sesr_x2", 0)
+    e = sesrq.Engine(bundle_from_oracle(net), _dev())
+    x = torch.from_numpy(rand_frame((1, 3, 1080, 1920), 2)).to(_dev())
+    q, y = e.forward(x)
+    q2, _ = e.forward(x)
+    assert torch.equal(q, q2)
+    y0, x0, h, w = 500, 900, 64, 96
+    crop = x[:, :, y0 - 7:y0 + h + 7, x0 - 7:x0 + w + 7].contiguous()
+    qc, _ = e.forward(crop)
+    assert torch.equal(qc[:, :, 14:14 + 2 * h, 14:14 + 2 * w], q[:, :, 2 * y0:2 * (y0 + h), 2 * x0:2 * (x0 + w)])
+    want = O.forward(net, crop.cpu().numpy())
+    _cmp("crop vs oracle", qc, want["q_out"])
+    xb = torch.cat([x[:, :, :270, :480], x[:, :, 270:540, 480:960]], 0).contiguous()
+    qb, _ = e.forward(xb)
+    qa0, _ = e.forward(xb[0:1].contiguous())
+    qa1, _ = e.forward(xb[1:2].contiguous())
+    assert torch.equal(qb[0:1], qa0) and torch.equal(qb[1:2], qa1)
+
+
+def test_error_conventions():
+    net = O.synth_net("nrdm", 0)
+    b = bundle_from_oracle(net)
+    e = sesrq.Engine(b, _dev())
+    with pytest.raises(ValueError, match="dimension"):
+        e.forward(torch.zeros(3, 8, 8, device=_dev()))
+    with pytest.raises(ValueError, match="channels"):
+        e.forward(torch.zeros(1, 1, 8, 8, device=_dev()))
+    bad = bundle_from_oracle(net)
+    bad.layers[1].M = 1 << 16
+    with pytest.raises(ValueError, match="requant"):
+        sesrq.Engine(bad, _dev())
+    bad = bundle_from_oracle(net)
+    bad.pe_num = 8
+    with pytest.raises(ValueError, match="pe_num"):
+        sesrq.Engine(bad, _dev())
