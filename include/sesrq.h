@@ -107,6 +107,14 @@ int sesrq_forward_debug(const sesrq_net *net, const void *in, int in_dtype, void
                         int N, int H, int W, void *workspace, size_t workspace_bytes, void *stream,
                         const sesrq_taps *taps);
 
+/* Measurement hook: runs `iters` forwards back to back on `stream` with a HIP event pair around
+ * every layer launch (events recorded on the same stream as the kernels), synchronises once at
+ * the end and returns the AVERAGE device time per layer launch in layer_ms[0..L-1] (ms) and the
+ * average time of a whole forward in *forward_ms.  Not part of the hot path. */
+int sesrq_forward_timed(const sesrq_net *net, const void *in, int in_dtype, void *out_q, void *out_f,
+                        int N, int H, int W, void *workspace, size_t workspace_bytes, void *stream,
+                        int iters, float *layer_ms, float *forward_ms);
+
 /* Name of the kernel family the net resolved to for layer k ("dot4-general", "mfma-merged", ...). */
 const char *sesrq_layer_engine(const sesrq_net *net, int k);
 

@@ -220,8 +220,8 @@ size_t sesrq_workspace_bytes(const sesrq_net *net, int N, int H, int W) {
     return ws_layout(net, N, H, W).total;
 }
 
-int sesrq_forward_debug(const sesrq_net *net, const void *in, int in_dtype, void *out_q, void *out_f, int N, int H, int W,
-                        void *workspace, size_t workspace_bytes, void *stream, const sesrq_taps *taps) {
+static int forward_impl(const sesrq_net *net, const void *in, int in_dtype, void *out_q, void *out_f, int N, int H, int W,
+                        void *workspace, size_t workspace_bytes, void *stream, const sesrq_taps *taps, hipEvent_t *ev) {
     if (!net || !in || !workspace) { set_error("sesrq_forward: null argument"); return 1; }
     if (!out_q && !out_f) { set_error("sesrq_forward: both outputs are NULL"); return 1; }
     if (N < 1 || H < 1 || W < 1) { set_error("sesrq_forward: N, H, W must be positive"); return 1; }
@@ -262,15 +262,53 @@ int sesrq_forward_debug(const sesrq_net *net, const void *in, int in_dtype, void
                 set_error("sesrq_forward: debug unpack launch failed"); return 1;
             }
         }
+        if (ev && hipEventRecord(ev[2 * k], st) != hipSuccess) { set_error("hipEventRecord failed"); return 1; }
         if (launch_dot4(eff, a, src, epi, st)) return 1;
+        if (ev && hipEventRecord(ev[2 * k + 1], st) != hipSuccess) { set_error("hipEventRecord failed"); return 1; }
         cur = dst;
     }
     return 0;
 }
 
+int sesrq_forward_debug(const sesrq_net *net, const void *in, int in_dtype, void *out_q, void *out_f, int N, int H, int W,
+                        void *workspace, size_t workspace_bytes, void *stream, const sesrq_taps *taps) {
+    return forward_impl(net, in, in_dtype, out_q, out_f, N, H, W, workspace, workspace_bytes, stream, taps, nullptr);
+}
+
 int sesrq_forward(const sesrq_net *net, const void *in, int in_dtype, void *out_q, void *out_f, int N, int H, int W,
                   void *workspace, size_t workspace_bytes, void *stream) {
-    return sesrq_forward_debug(net, in, in_dtype, out_q, out_f, N, H, W, workspace, workspace_bytes, stream, nullptr);
+    return forward_impl(net, in, in_dtype, out_q, out_f, N, H, W, workspace, workspace_bytes, stream, nullptr, nullptr);
+}
+
+int sesrq_forward_timed(const sesrq_net *net, const void *in, int in_dtype, void *out_q, void *out_f, int N, int H, int W,
+                        void *workspace, size_t workspace_bytes, void *stream, int iters, float *layer_ms, float *forward_ms) {
+    if (!net || iters < 1 || !layer_ms) { set_error("sesrq_forward_timed: bad argument"); return 1; }
+    const int L = net->L;
+    std::vector<hipEvent_t> ev((size_t)2 * L * iters);
+    for (auto &e : ev) HIP_OK(hipEventCreate(&e));
+    int rc = 0;
+    for (int it = 0; it < iters && !rc; ++it)
+        rc = forward_impl(net, in, in_dtype, out_q, out_f, N, H, W, workspace, workspace_bytes, stream, nullptr,
+                          ev.data() + (size_t)2 * L * it);
+    if (!rc && hipStreamSynchronize((hipStream_t)stream) != hipSuccess) { set_error("hipStreamSynchronize failed"); rc = 1; }
+    if (!rc) {
+        for (int k = 0; k < L; ++k) layer_ms[k] = 0.f;
+        double fw = 0;
+        for (int it = 0; it < iters; ++it) {
+            hipEvent_t *e = ev.data() + (size_t)2 * L * it;
+            for (int k = 0; k < L; ++k) {
+                float ms = 0.f;
+                (void)hipEventElapsedTime(&ms, e[2 * k], e[2 * k + 1]);
+                layer_ms[k] += ms / iters;
+            }
+            float ms = 0.f;
+            (void)hipEventElapsedTime(&ms, e[0], e[2 * L - 1]);
+            fw += ms;
+        }
+        if (forward_ms) *forward_ms = (float)(fw / iters);
+    }
+    for (auto &e : ev) (void)hipEventDestroy(e);
+    return rc;
 }
 
 /* ---------------------------------------------------------------- host scalar code */

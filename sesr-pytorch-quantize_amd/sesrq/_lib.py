@@ -46,6 +46,9 @@ SYMBOLS = {
                                 C.c_void_p, C.c_size_t, C.c_void_p]),
     "sesrq_forward_debug": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
                                       C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.POINTER(Taps)]),
+    "sesrq_forward_timed": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
+                                      C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_int, C.POINTER(C.c_float),
+                                      C.POINTER(C.c_float)]),
     "sesrq_layer_engine": (C.c_char_p, [C.c_void_p, C.c_int]),
     "sesrq_requant_const": (C.c_int, [C.c_double, C.c_int, C.c_int, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     "sesrq_quantize_weight": (C.c_int, [C.POINTER(C.c_float), C.c_size_t, C.c_int, C.POINTER(C.c_int8),
@@ -68,6 +71,14 @@ def lib() -> C.CDLL:
             raise RuntimeError(
                 f"sesrq: native library not found at {LIB_PATH}. Build it with "
                 "`make -C sesr-pytorch-quantize_amd/csrc` (or __graft_entry__.build()); there is no fallback path.")
+        # PyTorch-ROCm wheels bundle their own libamdhip64 (SONAME libamdhip64.so.7, needed by torch as
+        # "libamdhip64.so").  Loading libsesrq.so first would pull /opt/rocm's copy in and torch would then
+        # load a SECOND runtime; importing torch first makes the loader satisfy our NEEDED entry by SONAME
+        # with the runtime torch already mapped -> one HIP runtime per process, shared streams/pointers.
+        try:
+            import torch  # noqa: F401
+        except ImportError:  # standalone C/C++ use of the library: system runtime only
+            pass
         handle = C.CDLL(LIB_PATH)
         for name, (res, args) in SYMBOLS.items():
             fn = getattr(handle, name)          # AttributeError if the .so lacks a declared symbol

@@ -110,6 +110,21 @@ class Engine:
 
     __call__ = forward
 
+    def forward_timed(self, x: torch.Tensor, iters: int = 10):
+        """Measurement hook (sesrq_forward_timed): average device ms per layer launch and per forward."""
+        dt = self._check_in(x)
+        x = x.contiguous()
+        N, _, H, W = x.shape
+        shp = self.out_shape(N, H, W)
+        out_q = torch.empty(shp, dtype=torch.int8, device=self.device)
+        ws = self.workspace(N, H, W)
+        st = torch.cuda.current_stream(self.device).cuda_stream
+        layer_ms = (C.c_float * self.bundle.L)()
+        fwd = C.c_float()
+        _lib.check(_lib.lib().sesrq_forward_timed(self._h, x.data_ptr(), dt, out_q.data_ptr(), None, N, H, W,
+                                                  ws.data_ptr(), ws.numel(), st, iters, layer_ms, C.byref(fwd)))
+        return list(layer_ms), float(fwd.value)
+
     def forward_debug(self, x: torch.Tensor, pe: bool = True):
         """Forward with the reference's dump taps (define.py *_W_FLG): returns a dict with
         q_out, y, input{k} (int8 NCHW), pe_out{k} (N,4,OC,H,W int32), pe_add{k} (N,OC,H,W int32)."""

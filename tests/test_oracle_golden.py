@@ -70,3 +70,28 @@ def test_parameter_derivation(path):
         np.testing.assert_array_equal(net.layers[k].add_const, fx[f"add_const{k}"], err_msg=f"add_const{k}")
         assert (net.layers[k].M, net.layers[k].n) == (meta["M"][k], meta["n"][k])
     assert (net.M_res, net.n_res) == (meta["M_res"], meta["n_res"])
+
+
+@pytest.mark.parametrize("path", STAGE_FILES, ids=[os.path.basename(p)[:-4] for p in STAGE_FILES])
+def test_c_oracle_matches_reference(path):
+    """oracle/sesrq_oracle.c (the timed CPU baseline 'port') against the same golden vectors."""
+    from oracle import c_oracle as CO
+    fx, meta = load_fixture(path)
+    net = O.net_from_fixture(fx)
+    r = CO.forward(net, fixture_input(fx, meta), keep=True)
+    for k in range(5):
+        for nm in (f"input{k}", f"pe_out{k}", f"pe_add{k}"):
+            assert _sha(r[nm]) == meta["sha"][nm], nm
+    assert _sha(r["y"]) == meta["sha"]["out"]
+    assert _sha(O.forward(net, fixture_input(fx, meta))["q_out"]) == _sha(r["q_out"])
+
+
+def test_c_oracle_vs_numpy_oracle_batches_and_depth():
+    from oracle import c_oracle as CO
+    rng = np.random.default_rng(5)
+    for kind, nb, hard in (("sesr_x2", 3, True), ("nrdm", 6, False), ("sesr_x4", 3, True)):
+        net = O.synth_net(kind, 3, n_blocks=nb, hard=hard)
+        x = rng.random((2, net.layers[0].wq.shape[1], 19, 23), dtype=np.float32)
+        a, b = O.forward(net, x), CO.forward(net, x, threads=2)
+        np.testing.assert_array_equal(a["q_out"], b["q_out"])
+        np.testing.assert_array_equal(a["y"], b["y"])
