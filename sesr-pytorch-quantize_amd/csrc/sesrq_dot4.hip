@@ -69,8 +69,6 @@ __global__ __launch_bounds__(256) void conv_dot4_kernel(const ConvArgs a) {
                         q = reinterpret_cast<const signed char *>(a.in)[off];
                     }
                     word |= (q & 0xff) << (8 * c);
-                    if (a.dbg_q0 && ty >= R && ty < R + TH && tx >= R && tx < R + TW)
-                        a.dbg_q0[off] = (signed char)q;
                 }
             }
             lds[i] = word;
@@ -116,6 +114,14 @@ __global__ __launch_bounds__(256) void conv_dot4_kernel(const ConvArgs a) {
     const int gx = x0 + lx, gy = y0 + ly;
     if (gx >= W || gy >= H) return;
     const size_t pix = (size_t)n * HW + (size_t)gy * W + gx;
+    // (all global stores come after the last weight load, so the weight loads stay scalar)
+    if constexpr (SRC != SRC_NHWC16) {
+        if (a.dbg_q0) {
+            const int word = lds[(ly + R) * SW + lx + R];
+            for (int c = 0; c < a.ic; ++c)
+                a.dbg_q0[((size_t)n * a.ic + c) * HW + (size_t)gy * W + gx] = (signed char)((word >> (8 * c)) & 0xff);
+        }
+    }
 
     // ---- epilogue
     float t[OCP];
