@@ -76,6 +76,55 @@ static bool saturation_free(const sesrq_layer_desc &d, int zc, int acc_bits, int
     return ok;
 }
 
+// A-operand fragments of the MFMA engine.  Layout: 4 x int4 header = add constants in output-row
+// order, then F fragments of 64 lanes x 16 bytes.  Lane (m = lane & 15, g = lane >> 4), byte b of
+// fragment f carries W[ocmap(m)][ch][ky][kx] for the (ky, kx, ch) the kernel's B operand puts in
+// the same (g, b) slot -- the tables below are the single source of truth for both sides
+// (kernels: sesrq_mfma.hip).
+static void pack_mfma_frags(const sesrq_layer_desc &d, int kind, bool general, bool last, std::vector<int> &out) {
+    const int taps = d.k * d.k;
+    int F = 0;
+    switch (kind) {
+        case MFMA_H3: F = general ? 4 : 3; break;
+        case MFMA_H5: F = general ? 8 : 10; break;
+        case MFMA_F5: F = general ? 12 : 3; break;
+    }
+    out.assign((size_t)16 + (size_t)F * 64 * 4, 0);
+    auto ocmap = [&](int m) { return last ? m : (m >> 2) + 4 * (m & 3); };
+    for (int m = 0; m < 16; ++m) out[m] = ocmap(m) < d.oc ? d.add_const[ocmap(m)] : 0;
+    auto chmap16 = [](int b) { return (b >> 2) + 4 * (b & 3); };
+    signed char *bytes = reinterpret_cast<signed char *>(out.data() + 16);
+    for (int f = 0; f < F; ++f)
+        for (int lane = 0; lane < 64; ++lane)
+            for (int b = 0; b < 16; ++b) {
+                const int m = lane & 15, g = lane >> 4, i = b >> 2, j = b & 3;
+                int ky = -1, kx = -1, ch = -1;
+                if (kind == MFMA_H3 && !general) { ky = f; kx = g; ch = chmap16(b); if (g > 2) ky = -1; }
+                else if (kind == MFMA_H3) { const int p = f; ky = g; kx = i; ch = p + 4 * j; if (g > 2 || i > 2) ky = -1; }
+                else if (kind == MFMA_H5 && !general) { ky = f >> 1; kx = 4 * (f & 1) + g; ch = chmap16(b); if (kx > 4) ky = -1; }
+                else if (kind == MFMA_H5) {
+                    const int fi = f >> 2, p = f & 3;
+                    ch = p + 4 * j;
+                    if (fi == 0) { ky = g; kx = i; }
+                    else if (g == 0) { ky = 4; kx = i; }
+                    else if (g == 1) { ky = i; kx = 4; }
+                    else if (g == 2 && i == 0) { ky = 4; kx = 4; }
+                } else if (kind == MFMA_F5) {
+                    const int npe = general ? 4 : 1, fi = f / npe, p = f % npe;
+                    static const int tky[3][4] = {{0, 1, 2, 3}, {4, 0, 1, 2}, {3, 4, -1, -1}};
+                    static const int tsg[3][4] = {{0, 0, 0, 0}, {0, 1, 1, 1}, {1, 1, 0, 0}};
+                    ky = tky[fi][g]; kx = 4 * tsg[fi][g] + i; ch = j;
+                    if (kx > 4) ky = -1;
+                    if (general && ch != p) ky = -1;
+                }
+                const int oc = ocmap(m);
+                int w = 0;
+                if (ky >= 0 && ky < d.k && kx >= 0 && kx < d.k && ch >= 0 && ch < d.ic && oc < d.oc)
+                    w = d.w[((size_t)oc * d.ic + ch) * taps + ky * d.k + kx];
+                bytes[((size_t)f * 64 + lane) * 16 + b] = (signed char)w;
+            }
+}
+
 static int replicate_byte(int v) {
     const int b = v & 0xff;
     return b | (b << 8) | (b << 16) | (b << 24);
@@ -167,6 +216,23 @@ int sesrq_create(const sesrq_net_desc *d, sesrq_net **out) {
             sesrq_destroy(net);
             return 1;
         }
+        lp.mfma_kind = MFMA_NONE;
+        if (k == 0) { if (l.k == 5 && l.ic <= 4) lp.mfma_kind = MFMA_F5; }
+        else if (l.k == 3 && k < L - 1) lp.mfma_kind = MFMA_H3;
+        else if (l.k == 5) lp.mfma_kind = MFMA_H5;
+        if (lp.mfma_kind != MFMA_NONE) {
+            for (int gen = 0; gen < 2; ++gen) {
+                std::vector<int> fr;
+                pack_mfma_frags(l, lp.mfma_kind, gen == 1, k == L - 1, fr);
+                int4 **dst = gen ? &lp.d_afrag_general : &lp.d_afrag_merged;
+                if (hipMalloc((void **)dst, fr.size() * sizeof(int)) != hipSuccess ||
+                    hipMemcpy(*dst, fr.data(), fr.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess) {
+                    set_error("sesrq_create: device upload failed");
+                    sesrq_destroy(net);
+                    return 1;
+                }
+            }
+        }
         ConvArgs &a = lp.base;
         memset(&a, 0, sizeof(a));
         a.ic = l.ic; a.oc = l.oc;
@@ -183,7 +249,10 @@ int sesrq_create(const sesrq_net_desc *d, sesrq_net **out) {
         a.s_out = d->scale_out; a.z_out = (float)d->zero[L];
         a.ps = d->pixel_shuffle;
         for (int o = 0; o < l.oc; ++o) a.add_const[o] = l.add_const[o];
-        lp.engine = lp.general ? "dot4-general" : "dot4-merged";
+        lp.engine_dot4 = lp.general ? "dot4-general" : "dot4-merged";
+        static const char *kn[] = {"", "mfma-h3", "mfma-h5", "mfma-f5"};
+        lp.engine_mfma = lp.mfma_kind == MFMA_NONE ? lp.engine_dot4 : std::string(kn[lp.mfma_kind]) + (lp.general ? "-general" : "-merged");
+        lp.engine = lp.engine_mfma;
     }
     *out = net;
     return 0;
@@ -194,6 +263,8 @@ void sesrq_destroy(sesrq_net *net) {
     for (auto &lp : net->layers) {
         if (lp.d_wpk_general) (void)hipFree(lp.d_wpk_general);
         if (lp.d_wpk_merged) (void)hipFree(lp.d_wpk_merged);
+        if (lp.d_afrag_general) (void)hipFree(lp.d_afrag_general);
+        if (lp.d_afrag_merged) (void)hipFree(lp.d_afrag_merged);
     }
     delete net;
 }
@@ -203,7 +274,9 @@ int sesrq_set_option(sesrq_net *net, int option, int value) {
     switch (option) {
         case SESRQ_OPT_ENGINE:
             if (value < SESRQ_ENGINE_AUTO || value > SESRQ_ENGINE_MFMA) { set_error("sesrq_set_option: bad engine"); return 1; }
-            net->engine = value; return 0;
+            net->engine = value;
+            for (auto &lp : net->layers) lp.engine = (value == SESRQ_ENGINE_DOT4) ? lp.engine_dot4 : lp.engine_mfma;
+            return 0;
         case SESRQ_OPT_FORCE_GENERAL: net->force_general = value ? 1 : 0; return 0;
     }
     set_error("sesrq_set_option: unknown option");
@@ -263,7 +336,11 @@ static int forward_impl(const sesrq_net *net, const void *in, int in_dtype, void
             }
         }
         if (ev && hipEventRecord(ev[2 * k], st) != hipSuccess) { set_error("hipEventRecord failed"); return 1; }
-        if (launch_dot4(eff, a, src, epi, st)) return 1;
+        const bool use_mfma = net->engine != SESRQ_ENGINE_DOT4 && lp.mfma_kind != MFMA_NONE && !dbg;
+        if (use_mfma) {
+            a.afrag = eff.general ? lp.d_afrag_general : lp.d_afrag_merged;
+            if (launch_mfma(lp, a, src, epi, eff.general, st)) return 1;
+        } else if (launch_dot4(eff, a, src, epi, st)) return 1;
         if (ev && hipEventRecord(ev[2 * k + 1], st) != hipSuccess) { set_error("hipEventRecord failed"); return 1; }
         cur = dst;
     }

@@ -11,6 +11,7 @@ namespace sesrq {
 
 enum Epi { EPI_MID = 0, EPI_PRERES = 1, EPI_LAST = 2 };
 enum Src { SRC_NHWC16 = 0, SRC_F32 = 1, SRC_I8 = 2 };
+enum MfmaKind { MFMA_NONE = 0, MFMA_H3 = 1, MFMA_H5 = 2, MFMA_F5 = 3 };
 
 // Per-launch arguments of one conv layer.  Lives in the kernarg segment (SGPR loads).
 struct ConvArgs {
@@ -20,7 +21,8 @@ struct ConvArgs {
     void *rc_out;            // layer 0 only, when zero[1] != -128: separate rc tensor (else NULL)
     void *out_q;             // EPI_LAST: (N, C, H*r, W*r) int8 or NULL
     float *out_f;            // EPI_LAST: same shape fp32 or NULL
-    const int *wpk;          // packed weights [tap][OCP][4] dwords (see pack_weights)
+    const int *wpk;          // dot4: packed weights [tap][OCP][4] dwords (see pack_weights)
+    const int4 *afrag;       // mfma: [4] add-constant words (row order) + A fragments [F][64] (pack_mfma_frags)
     int *dbg_pe;             // (N,4,OC,H,W) int32 or NULL
     int *dbg_add;            // (N,OC,H,W) int32 or NULL
     signed char *dbg_q0;     // (N,IC,H,W) int8: quantised input of layer 0 or NULL
@@ -45,6 +47,10 @@ struct LayerPlan {
     std::string engine;
     int *d_wpk_general = nullptr;   // device
     int *d_wpk_merged = nullptr;    // device
+    int mfma_kind = MFMA_NONE;
+    int4 *d_afrag_general = nullptr; // device
+    int4 *d_afrag_merged = nullptr;  // device
+    std::string engine_dot4, engine_mfma;
     ConvArgs base;           // constant fields prefilled
     // static saturation analysis (per layer)
     long long worst_pe = 0, worst_sum = 0;
@@ -54,6 +60,8 @@ void set_error(const std::string &msg);
 
 // dot4 engine
 int launch_dot4(const LayerPlan &lp, const ConvArgs &a, int src, int epi, hipStream_t st);
+// mfma engine
+int launch_mfma(const LayerPlan &lp, const ConvArgs &a, int src, int epi, bool general, hipStream_t st);
 int launch_unpack_nhwc16(const void *nhwc, signed char *nchw, int N, int C, int H, int W, hipStream_t st);
 
 }  // namespace sesrq
