@@ -9,7 +9,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.normpath(os.path.join(_HERE, "..", "lib", "libsesrq.so"))
+# SESRQ_LIB selects another build of the same ABI (A/B kernel experiments); never a fallback.
+LIB_PATH = os.environ.get("SESRQ_LIB") or os.path.normpath(os.path.join(_HERE, "..", "lib", "libsesrq.so"))
 
 MAX_LAYERS = 16
 MAX_CH = 16
