@@ -70,16 +70,13 @@ def main():
     from sesrq import _lib
     from sesrq.bundle import Bundle
 
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
+    from sesrq.dist import Group, env_world
+    rank, local, world = env_world()
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device")
     torch.cuda.set_device(local)
     dev = torch.device(f"cuda:{local}")
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+    grp = Group(backend="nccl", device=dev)      # RCCL; only the timing fence uses it
 
     fixture, cin, H, W, desc = WORKLOADS[args.workload]
     bundle = Bundle.load(os.path.join(ROOT, "tests", "golden", fixture))
@@ -93,8 +90,7 @@ def main():
         eng.forward(x, want_q=True, want_f=False, out_q=out_q)
 
     def fence():
-        if dist is not None:
-            dist.barrier()
+        grp.barrier()
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
@@ -104,11 +100,7 @@ def main():
     for _ in range(args.steps):
         step()
     fence()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = grp.max_over_ranks(time.perf_counter() - t0)
 
     result = None
     if rank == 0:
@@ -164,9 +156,7 @@ def main():
                              "weights": f"reference random-init net, calibrated by the reference ({fixture})",
                              "sharding": f"frames x{world}, no collective", "engines": eng.layer_engines()},
                   "roofline": roofline, "cpu_baseline": cpu, "parity": parity}
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+    grp.close()
     if result is not None:
         print(json.dumps(result), flush=True)
 

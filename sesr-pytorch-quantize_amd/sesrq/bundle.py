@@ -119,12 +119,24 @@ def derive_bundle(weights: Sequence[np.ndarray], biases: Sequence[np.ndarray], s
 
     Layer roles by position, as in myQL/quan_func.py:523-609: layers 0 and L-2 requantise into
     domain 1, layer L-1 into domain L, the rest into k+1; residual multiplier s_1/s_{L-1}."""
-    L = len(weights)
+    quantised = [quantize_weight(w, quan_bit) for w in weights]
+    return derive_bundle_from_quantized([q for q, _ in quantised], [s for _, s in quantised], biases, scale, zero,
+                                        pixel_shuffle, name=name, bias_bit=bias_bit, requan_bit=requan_bit,
+                                        requan_n_max=requan_n_max, pe_num=pe_num, pe_acc_bits=pe_acc_bits,
+                                        pe_add_bits=pe_add_bits)
+
+
+def derive_bundle_from_quantized(wqs: Sequence[np.ndarray], w_scales: Sequence[float], biases: Sequence[np.ndarray],
+                                 scale: Sequence[float], zero: Sequence[int], pixel_shuffle: int, name: str = "",
+                                 bias_bit: int = 16, requan_bit: int = 16, requan_n_max: int = 32, pe_num: int = 4,
+                                 pe_acc_bits: int = 18, pe_add_bits: int = 20) -> Bundle:
+    """Same as derive_bundle for weights that quantize_model_weight already turned into integers."""
+    L = len(wqs)
     if len(scale) != L + 1 or len(zero) != L + 1:
         raise ValueError("derive_bundle: need L+1 scales and zeros")
     layers = []
     for k in range(L):
-        wq, sw = quantize_weight(weights[k], quan_bit)
+        wq, sw = np.ascontiguousarray(wqs[k], dtype=np.int8), float(w_scales[k])
         nxt = 1 if k in (0, L - 2) else k + 1
         M, n = requant_const(scale[k] / scale[nxt] * sw, requan_bit, requan_n_max)
         layers.append(LayerParams(wq=wq, add_const=add_const(biases[k], wq, scale[k], zero[k], sw, bias_bit),

@@ -1,0 +1,148 @@
+"""Lowering of a spliced fx graph to the fused device op.
+
+A graph produced by myQL.graph_modify in exe_mode 1 is a straight chain
+    [quantize_asymmetrical_by_tensor -> reshape_input_for_hardware_pe -> Conv2d -> PEs_and_bias_adder
+     -> requan_conv2d_output -> ReLU|Identity] x L  (-> PixelShuffle)
+(reference: sim.py:82-114 builds it, sim.py:205 runs it).  lower() checks that shape, collects the
+integer weights, the float biases carried by the bias-bypass nodes, the calibrated activation
+domains from the parameter store, derives the integer bundle through libsesrq's host entry points
+and returns it; SesrqGraphModule.forward then runs sesrq_forward on the frame."""
+from __future__ import annotations
+
+import numpy as np
+import torch
+from torch import nn
+
+from .bundle import Bundle, derive_bundle_from_quantized
+from .store import STORE
+
+_STAGE_ORDER_IN = ("quantize_asymmetrical_by_tensor", "reshape_input_for_hardware_pe")
+_STAGE_ORDER_OUT = ("PEs_and_bias_adder", "requan_conv2d_output")
+
+
+def _fname(node):
+    return getattr(node.target, "__name__", None) if node.op == "call_function" else None
+
+
+def _single_user(node):
+    users = list(node.users)
+    if len(users) != 1:
+        raise RuntimeError(f"sesrq lowering: node '{node.name}' must have exactly one user, has {len(users)}")
+    return users[0]
+
+
+def lower(gm: torch.fx.GraphModule, store=STORE) -> Bundle:
+    modules = dict(gm.named_modules())
+    convs = [n for n in gm.graph.nodes if n.op == "call_module" and type(modules[n.target]) is nn.Conv2d]
+    if len(convs) < 3:
+        raise RuntimeError("sesrq lowering: need at least 3 convolutions")
+    L = len(convs)
+    wq, wsc, biases, relu = [], [], [], []
+    widths = None
+    prev_tail = None
+    for k, c in enumerate(convs):
+        # ---- stages in front of the conv
+        r = c.args[0]
+        if _fname(r) != _STAGE_ORDER_IN[1]:
+            raise RuntimeError(f"sesrq lowering: conv {k} is not fed by reshape_input_for_hardware_pe "
+                               "(splice order: quantize-before, then reshape-before; sim.py:89-100)")
+        q = r.args[0]
+        if _fname(q) != _STAGE_ORDER_IN[0]:
+            raise RuntimeError(f"sesrq lowering: conv {k} lacks quantize_asymmetrical_by_tensor in front of the PE split")
+        if q.kwargs.get("exe_mode") != 1 or q.kwargs.get("func_id") != k or q.kwargs.get("width") != 8:
+            raise RuntimeError(f"sesrq lowering: conv {k}: quantiser must be exe_mode=1, width=8, func_id={k} "
+                               f"(got {dict(q.kwargs)}); exe_mode 0 (calibration) is not lowered")
+        if int(r.kwargs.get("pe_num", 4)) != 4:
+            raise RuntimeError("sesrq lowering: pe_num must be 4")
+        src = q.args[0]
+        if k == 0:
+            if src.op != "placeholder":
+                raise RuntimeError("sesrq lowering: first conv chain must start at the graph input")
+        elif src is not prev_tail:
+            raise RuntimeError(f"sesrq lowering: conv {k} is not fed by the previous chain (non-sequential graph)")
+        # ---- stages behind the conv
+        pb = _single_user(c)
+        if _fname(pb) != _STAGE_ORDER_OUT[0]:
+            raise RuntimeError(f"sesrq lowering: conv {k} is not followed by PEs_and_bias_adder (insert_bias_bypass)")
+        rq = _single_user(pb)
+        if _fname(rq) != _STAGE_ORDER_OUT[1]:
+            raise RuntimeError(f"sesrq lowering: conv {k}: PEs_and_bias_adder is not followed by requan_conv2d_output")
+        if pb.kwargs.get("exe_mode") != 1 or rq.kwargs.get("exe_mode") != 1:
+            raise RuntimeError("sesrq lowering: PEs_and_bias_adder / requan_conv2d_output must be exe_mode=1")
+        if pb.kwargs.get("func_id") != k or rq.kwargs.get("func_id") != k:
+            raise RuntimeError(f"sesrq lowering: conv {k}: stage func_id mismatch")
+        w = (int(pb.kwargs["pe_add_width"]), int(pb.kwargs["pe_acc_width"]), int(pb.kwargs["bias_width"]), int(pb.kwargs["pe_num"]))
+        if widths is None:
+            widths = w
+        elif w != widths:
+            raise RuntimeError("sesrq lowering: bit widths differ between layers")
+        tail = rq
+        act = list(rq.users)
+        is_relu = False
+        if len(act) == 1 and act[0].op == "call_module" and isinstance(modules[act[0].target], (nn.ReLU, nn.Identity)):
+            is_relu = isinstance(modules[act[0].target], nn.ReLU)
+            tail = act[0]
+        relu.append(is_relu)
+        prev_tail = tail
+        # ---- parameters
+        mod = modules[c.target]
+        if mod.stride != (1, 1) or mod.dilation != (1, 1) or mod.groups != 1 or mod.kernel_size[0] != mod.kernel_size[1] \
+                or mod.padding != (mod.kernel_size[0] // 2,) * 2:
+            raise RuntimeError(f"sesrq lowering: conv {k} must be stride-1 'same' k x k")
+        wt = mod.weight.detach().cpu().numpy()
+        if not np.array_equal(wt, np.rint(wt)) or wt.min() < -128 or wt.max() > 127:
+            raise RuntimeError(f"sesrq lowering: conv {k} weights are not INT8-valued; run "
+                               "quantize_model_weight(model, 8, 1) before splicing (sim.py:85)")
+        wq.append(wt.astype(np.int8))
+        wsc.append(float(store[f"weight/conv.weight.{k}.scale"]))
+        biases.append(np.asarray(pb.kwargs["bias"], dtype=np.float32))
+    ps = 1
+    users = list(prev_tail.users)
+    if len(users) == 1 and users[0].op == "call_module" and isinstance(modules[users[0].target], nn.PixelShuffle):
+        ps = int(modules[users[0].target].upscale_factor)
+        users = list(users[0].users)
+    if len(users) != 1 or users[0].op != "output":
+        raise RuntimeError("sesrq lowering: unexpected operations after the last conv chain")
+    if relu[-1] or not all(relu[:-1]):
+        raise RuntimeError("sesrq lowering: expected ReLU after every conv but the last (reference topologies)")
+    scale, zero = store.activation_domains(L)
+    pe_add, pe_acc, bias_w, pe_num = widths
+    import define
+    return derive_bundle_from_quantized(wq, wsc, biases, scale, zero, ps, name=type(gm).__name__, bias_bit=bias_w,
+                                        requan_bit=define.REQUAN_BIT, requan_n_max=define.REQUAN_N_MAX, pe_num=pe_num,
+                                        pe_acc_bits=pe_acc, pe_add_bits=pe_add)
+
+
+class SesrqGraphModule(torch.fx.GraphModule):
+    """GraphModule whose forward is the fused device op.  `last_q` keeps the int8 result (input.L.pt
+    after PixelShuffle) of the most recent call; the return value is the reference's float tensor."""
+
+    def _sesrq_engine(self, device):
+        cache = self.__dict__.setdefault("_sesrq_cache", {})
+        key = str(device)
+        if key not in cache:
+            from .engine import Engine
+            bundle = lower(self)
+            cache[key] = Engine(bundle, device)
+        return cache[key]
+
+    def sesrq_bundle(self) -> Bundle:
+        return lower(self)
+
+    def recompile(self):
+        # GraphModule installs the generated python forward on the per-instance class; put the fused
+        # device forward back on top of it (the generated code stays available as `self.code`).
+        out = super().recompile()
+        type(self).forward = SesrqGraphModule._fused_forward
+        return out
+
+    def _fused_forward(self, x):
+        if not isinstance(x, torch.Tensor) or x.dim() != 4:
+            raise ValueError('Expect input tensor dimension: 4, but get %d' % (x.dim() if isinstance(x, torch.Tensor) else -1))
+        if not x.is_cuda:
+            raise RuntimeError("sesrq: the integer path runs on the GPU only; move the frame to a HIP device "
+                               "(model(inps.cuda())) -- there is no CPU fallback")
+        eng = self._sesrq_engine(x.device)
+        q, y = eng.forward(x.float() if x.dtype != torch.int8 else x)
+        self.__dict__["last_q"] = q
+        return y

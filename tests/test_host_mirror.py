@@ -1,0 +1,124 @@
+"""Host-side mirror of the reference interface (define / myQL / models / sim): the spliced graph
+lowers to the integer bundle the reference itself produced (CPU-only: no device call), keeps the
+reference's error conventions, and -- on the GPU -- the spliced model's forward is the golden output."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN, load_fixture
+import define
+import sim
+from myQL import quan_func as qf
+from myQL.quan_classes import NodeInsertMapping, FunctionPackage, NodeInsertMappingElement
+from myQL.graph_modify import insert_before
+from models import sesr_sim, model_utils_pt
+from sesrq.store import STORE
+
+CASES = {"sesr_x4": 5, "nrdm_3": 3, "sesr_x2_rand": 6, "sesr_x4_qat": 5, "nrdm_3_qat": 3}
+
+
+@pytest.mark.parametrize("case", sorted(CASES))
+def test_spliced_graph_lowers_to_reference_bundle(case):
+    STORE.clear()
+    model = sim.splice(sim.float_model(CASES[case], params=os.path.join(GOLDEN, f"{case}.params.npz")))
+    names = [getattr(n.target, "__name__", str(n.target)) for n in model.graph.nodes]
+    # same chain the reference's generated forward shows
+    i = names.index("conv_first.conv_expand")
+    assert names[i - 2:i + 3] == ["quantize_asymmetrical_by_tensor", "reshape_input_for_hardware_pe",
+                                  "conv_first.conv_expand", "PEs_and_bias_adder", "requan_conv2d_output"]
+    b = model.sesrq_bundle()
+    fx, meta = load_fixture(os.path.join(GOLDEN, f"{case}.crop.npz"))
+    for k in range(5):
+        np.testing.assert_array_equal(b.layers[k].wq, fx[f"Wq{k}"])
+        np.testing.assert_array_equal(b.layers[k].add_const, fx[f"add_const{k}"])
+        assert (b.layers[k].M, b.layers[k].n) == (meta["M"][k], meta["n"][k])
+    assert (b.M_res, b.n_res) == (meta["M_res"], meta["n_res"])
+    assert b.pixel_shuffle == {5: 4, 3: 1, 6: 2}[CASES[case]]
+    assert b.zero == meta["zero"] and b.scale == meta["scale"]
+    # conv biases were zeroed by the bias bypass and travel as kwargs (graph_modify.py:68-120)
+    assert float(model.conv_first.conv_expand.bias.abs().max()) == 0.0
+
+
+def test_collapse_is_the_same_linear_map():
+    torch.manual_seed(0)
+    net = sesr_sim.sesr()
+    x = torch.rand(1, 1, 12, 14)
+    with torch.no_grad():
+        init = net.conv_first(x)
+        mid = net.residual_block(init)
+        want = net.depth_to_space(net.conv_last(mid))
+        net.collapse()
+        got = net(x)
+    assert got.shape == (1, 1, 48, 56)
+    np.testing.assert_allclose(got.numpy(), want.numpy(), rtol=1e-4, atol=1e-5)
+    assert isinstance(net.conv_first.conv_squeeze, torch.nn.Identity) and net.conv_first.conv_expand.weight.shape == (16, 1, 5, 5)
+
+
+@pytest.mark.skipif(not os.path.isfile("/root/reference/model_params/x4sesr.pth"), reason="reference checkpoint not present")
+def test_collapse_of_reference_checkpoint_matches_golden_float_weights():
+    """Build-container only: my closed-form fold vs the reference's delta-image fold on x4sesr.pth."""
+    m = sim.float_model(5, ckpt="/root/reference/model_params/x4sesr.pth")
+    z = np.load(os.path.join(GOLDEN, "sesr_x4.params.npz"))
+    convs = [m.conv_first.conv_expand] + [b.conv_expand for b in m.residual_block] + [m.conv_last.conv_expand]
+    for k, c in enumerate(convs):
+        np.testing.assert_allclose(c.weight.detach().numpy(), z[f"Wf{k}"], rtol=0, atol=2e-6)
+        np.testing.assert_allclose(c.bias.detach().numpy(), z[f"bf{k}"], rtol=0, atol=1e-7)
+
+
+def test_error_conventions_of_the_callables():
+    with pytest.raises(AssertionError, match="less than shift_max"):
+        qf.quan_layer_between_const(0.5, 16, 16)
+    assert qf.quan_layer_between_const(0.0078125) == (32768, 22)
+    with pytest.raises(AssertionError, match="all zero"):
+        qf.quantize_symmetrical_by_tensor(torch.zeros(2, 2, 3, 3), 8, 1, func_id=0)
+    with pytest.raises(AssertionError, match="dimension: 4"):
+        qf.reshape_input_for_hardware_pe(torch.zeros(3, 4, 5))
+    with pytest.raises(RuntimeError, match="stage marker"):
+        qf.requan_conv2d_output(torch.zeros(1, 1, 2, 2), func_id=0, exe_mode=1)
+    with pytest.raises(NotImplementedError, match="calibration"):
+        qf.quantize_asymmetrical_by_tensor(torch.zeros(1, 1, 2, 2), width=8, exe_mode=0, func_id=0)
+    assert qf.float_to_hex(-1, 8) == "ff" and qf.float_to_hex(127, 8) == "7f" and qf.float_to_hex(-131072, 18) == "20000"
+
+
+def test_partial_splice_is_rejected():
+    STORE.clear()
+    model = qf.quantize_model_weight(sim.float_model(5, params=os.path.join(GOLDEN, "sesr_x4.params.npz")), 8, 1)
+    m = NodeInsertMapping()
+    m.add_config(NodeInsertMappingElement(torch.nn.Conv2d, FunctionPackage(qf.quantize_asymmetrical_by_tensor, {"width": 8, "exe_mode": 1})))
+    gm = insert_before(model_input=model, insert_mapping=m, has_func_id=True)
+    with pytest.raises(RuntimeError, match="reshape_input_for_hardware_pe"):
+        gm.sesrq_bundle()
+    with pytest.raises(RuntimeError, match="GPU only"):
+        gm(torch.zeros(1, 1, 8, 8))
+
+
+def test_missing_calibration_is_reported():
+    STORE.clear()
+    model = sim.splice(sim.float_model(5, params=os.path.join(GOLDEN, "sesr_x4.params.npz")))
+    STORE.clear()
+    with pytest.raises(KeyError, match="parameter store"):
+        model.sesrq_bundle()
+
+
+def test_define_surface():
+    for name in ("MFLAG", "PE", "QUAN_BIT", "BIAS_BIT", "PE_ACC_BIT", "PE_ADD_BIT", "REQUAN_BIT", "REQUAN_N_MAX",
+                 "WEIGHT_W_FLG", "INPUT_W_FLG", "BIAS_W_FLG", "BIAS_QUAN_W_FLG", "OUTPUT_PE_W_FLG", "OUTPUT_PE_ADD_W_FLG",
+                 "REQUAN_FACTOR_W_FLG", "WEIGHT_W_HIST_PNG", "INPUT_W_HIST_PNG", "TEST_RAW_ADD_NOISE"):
+        assert hasattr(define, name)
+    assert (define.PE, define.QUAN_BIT, define.BIAS_BIT, define.PE_ACC_BIT, define.PE_ADD_BIT, define.REQUAN_BIT,
+            define.REQUAN_N_MAX) == (4, 8, 16, 18, 20, 16, 32)
+    define.check()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ["sesr_x4", "nrdm_3", "sesr_x2_rand"])
+def test_spliced_model_forward_is_the_golden_output(case):
+    STORE.clear()
+    model = sim.splice(sim.float_model(CASES[case], params=os.path.join(GOLDEN, f"{case}.params.npz")))
+    fx, meta = load_fixture(os.path.join(GOLDEN, f"{case}.crop.npz"))
+    y = model(torch.from_numpy(fx["x"]).cuda())
+    np.testing.assert_array_equal(y.cpu().numpy(), fx["out"])
+    assert model.last_q.dtype == torch.int8
