@@ -32,7 +32,7 @@ extern "C" {
 enum { SESRQ_F32 = 0, SESRQ_I8 = 1 };
 
 /* kernel families (sesrq_set_option(net, SESRQ_OPT_ENGINE, ...)) */
-enum { SESRQ_ENGINE_AUTO = 0, SESRQ_ENGINE_DOT4 = 1, SESRQ_ENGINE_MFMA = 2 };
+enum { SESRQ_ENGINE_AUTO = 0, SESRQ_ENGINE_DOT4 = 1, SESRQ_ENGINE_MFMA = 2, SESRQ_ENGINE_FUSED = 3 };
 enum { SESRQ_OPT_ENGINE = 1, SESRQ_OPT_FORCE_GENERAL = 2 };
 
 /* One collapsed convolution with its integer epilogue.

@@ -254,6 +254,11 @@ int sesrq_create(const sesrq_net_desc *d, sesrq_net **out) {
         lp.engine_mfma = lp.mfma_kind == MFMA_NONE ? lp.engine_dot4 : std::string(kn[lp.mfma_kind]) + (lp.general ? "-general" : "-merged");
         lp.engine = lp.engine_mfma;
     }
+    // fused engine: reference topology 5x5 / 3x3 x3 / 5x5, standard 18/20-bit PE model, z1 == -128
+    net->fused_ok = (L == 5) && net->layers[0].mfma_kind == MFMA_F5 && net->layers[1].mfma_kind == MFMA_H3 &&
+                    net->layers[2].mfma_kind == MFMA_H3 && net->layers[3].mfma_kind == MFMA_H3 &&
+                    net->layers[4].mfma_kind == MFMA_H5 && !net->rc_separate && d->pe_acc_bits == 18 && d->pe_add_bits == 20 &&
+                    d->layers[0].relu && d->layers[1].relu && d->layers[2].relu && d->layers[3].relu && !d->layers[4].relu;
     *out = net;
     return 0;
 }
@@ -273,7 +278,8 @@ int sesrq_set_option(sesrq_net *net, int option, int value) {
     if (!net) { set_error("sesrq_set_option: null net"); return 1; }
     switch (option) {
         case SESRQ_OPT_ENGINE:
-            if (value < SESRQ_ENGINE_AUTO || value > SESRQ_ENGINE_MFMA) { set_error("sesrq_set_option: bad engine"); return 1; }
+            if (value < SESRQ_ENGINE_AUTO || value > SESRQ_ENGINE_FUSED) { set_error("sesrq_set_option: bad engine"); return 1; }
+            if (value == SESRQ_ENGINE_FUSED && !net->fused_ok) { set_error("sesrq_set_option: this net is not eligible for the fused engine"); return 1; }
             net->engine = value;
             for (auto &lp : net->layers) lp.engine = (value == SESRQ_ENGINE_DOT4) ? lp.engine_dot4 : lp.engine_mfma;
             return 0;
@@ -283,8 +289,18 @@ int sesrq_set_option(sesrq_net *net, int option, int value) {
     return 1;
 }
 
+static bool use_fused(const sesrq_net *net, int in_dtype, const sesrq_taps *taps) {
+    return net->fused_ok && (net->engine == SESRQ_ENGINE_AUTO || net->engine == SESRQ_ENGINE_FUSED) && in_dtype == SESRQ_F32 && !taps;
+}
+
 const char *sesrq_layer_engine(const sesrq_net *net, int k) {
     if (!net || k < 0 || k >= net->L) return "";
+    if (net->fused_ok && (net->engine == SESRQ_ENGINE_AUTO || net->engine == SESRQ_ENGINE_FUSED)) {
+        static thread_local std::string s;
+        const bool gen = net->layers[k].general || net->force_general;
+        s = std::string("fused5-") + (gen ? "general" : "merged");
+        return s.c_str();
+    }
     return net->layers[k].engine.c_str();
 }
 
@@ -306,6 +322,38 @@ static int forward_impl(const sesrq_net *net, const void *in, int in_dtype, void
     hipStream_t st = (hipStream_t)stream;
     char *ws = (char *)workspace;
     const int L = net->L;
+    if (use_fused(net, in_dtype, taps)) {
+        FusedArgs f;
+        memset(&f, 0, sizeof(f));
+        f.in = in; f.out_q = out_q; f.out_f = (float *)out_f;
+        f.N = N; f.H = H; f.W = W;
+        f.ic = net->layers[0].ic; f.oc = net->layers[4].oc; f.ps = net->ps;
+        const int strips = (W + 63) / 64;
+        int nchunks = (int)((512 + (long long)strips * N / 2) / ((long long)strips * N));
+        nchunks = std::max(1, std::min(nchunks, (H + 15) / 16));
+        f.chunk = (H + nchunks - 1) / nchunks;
+        const ConvArgs &a0 = net->layers[0].base, &a4 = net->layers[4].base;
+        f.pad_in0 = a0.pad_word;
+        f.s_in = a0.s_in; f.z_in = a0.z_in; f.s_out = a4.s_out; f.z_out = a4.z_out;
+        f.Mres = a0.Mres; f.shres = a0.shres; f.z_merge = a0.z_merge;
+        bool gen[5];
+        for (int k = 0; k < 5; ++k) gen[k] = net->layers[k].general || net->force_general;
+        const bool genh = gen[1] || gen[2] || gen[3];
+        for (int k = 0; k < 5; ++k) {
+            const LayerPlan &lp = net->layers[k];
+            const bool g = (k == 0) ? gen[0] : (k == 4 ? gen[4] : genh);
+            f.l[k].afrag = g ? lp.d_afrag_general : lp.d_afrag_merged;
+            f.l[k].Mf = lp.base.Mf; f.l[k].sh = lp.base.sh; f.l[k].z_next = lp.base.z_next;
+            f.l[k].pad_next = (k < 4) ? net->layers[k + 1].base.pad_word : 0;
+        }
+        if (ev && hipEventRecord(ev[0], st) != hipSuccess) { set_error("hipEventRecord failed"); return 1; }
+        if (launch_fused5(f, gen[0], genh, gen[4], st)) return 1;
+        if (ev) {
+            for (int k = 1; k < 2 * L; ++k)
+                if (hipEventRecord(ev[k], st) != hipSuccess) { set_error("hipEventRecord failed"); return 1; }
+        }
+        return 0;
+    }
     // buffers: S = layer-0 output (kept for the residual), A/B ping-pong, RC optional
     void *bufS = ws + wl.off_s, *bufA = ws + wl.off_a, *bufB = ws + wl.off_b;
     void *bufRC = net->rc_separate ? (void *)(ws + wl.off_rc) : bufS;

@@ -27,6 +27,7 @@ struct ConvArgs {
     int *dbg_add;            // (N,OC,H,W) int32 or NULL
     signed char *dbg_q0;     // (N,IC,H,W) int8: quantised input of layer 0 or NULL
     int N, H, W;
+    int chunk_tiles;         // mfma engine: vertically adjacent tiles walked by one workgroup
     int ic, oc;              // real channel counts
     int pad_word;            // zc replicated into 4 bytes
     int acc_lo, acc_hi, add_lo, add_hi;
@@ -39,6 +40,22 @@ struct ConvArgs {
     int relu;
     int ps;                  // EPI_LAST pixel shuffle factor
     int add_const[SESRQ_MAX_CH];
+};
+
+// fused engine (sesrq_fused.hip): all five layers of the reference topology in one launch
+struct FusedLayer {
+    const int4 *afrag;       // same A-fragment image as the per-layer MFMA kernels
+    float Mf, sh, z_next;
+    int pad_next;            // pad word (zc bytes) of the NEXT layer's input
+};
+struct FusedArgs {
+    const void *in;
+    void *out_q;
+    float *out_f;
+    int N, H, W, ic, oc, ps, chunk;
+    int pad_in0;
+    float s_in, z_in, s_out, z_out, Mres, shres, z_merge;
+    FusedLayer l[5];
 };
 
 struct LayerPlan {
@@ -62,6 +79,7 @@ void set_error(const std::string &msg);
 int launch_dot4(const LayerPlan &lp, const ConvArgs &a, int src, int epi, hipStream_t st);
 // mfma engine
 int launch_mfma(const LayerPlan &lp, const ConvArgs &a, int src, int epi, bool general, hipStream_t st);
+int launch_fused5(const FusedArgs &a, bool gen0, bool genh, bool gen4, hipStream_t st);
 int launch_unpack_nhwc16(const void *nhwc, signed char *nchw, int N, int C, int H, int W, hipStream_t st);
 
 }  // namespace sesrq
@@ -78,4 +96,5 @@ struct sesrq_net {
     int force_general = 0;
     int device = 0;
     bool rc_separate = false;   // zero[1] != -128 -> layer 0 writes its own rc tensor
+    bool fused_ok = false;      // topology/parameters eligible for the fused engine
 };

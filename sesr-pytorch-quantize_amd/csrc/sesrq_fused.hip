@@ -1,0 +1,322 @@
+// sesrq fused engine: the whole 5-conv net in ONE kernel, intermediates never leave the CU.
+//
+// A workgroup (4 waves) owns a strip of 64 output columns x `chunk` rows and streams down the
+// frame one image row per step.  Every layer keeps the last few rows of its INPUT in an LDS ring
+// (NHWC16 int8, PE-major channel order, same pixel format as the per-layer engines):
+//
+//   fp32 frame row --quantise--> ring_in --L0 5x5--> ring1 --L1 3x3--> ring2 --L2 3x3--> ring3
+//        --L3 3x3 (+ long residual from ring1)--> ring4 --L4 5x5 + PixelShuffle--> HBM
+//
+// At step s the layers work on rows   rin = Y0-7+s,  r1 = rin-3,  r2 = r1-2,  r3 = r2-2,
+// r4 = r3-2,  ro = r4-3:  each layer only reads rows that were written in EARLIER steps, so one
+// __syncthreads() per step is the only synchronisation and the 24 row-tiles of a step (5 per
+// hidden layer over u = 0..79, 4 for the output over u = 8..71; u = 0 <-> x = x0-8) are dealt
+// round-robin to the four waves.  Columns/rows a layer computes but nobody needs (the shrinking
+// halo) hold garbage that never reaches a needed output; pixels OUTSIDE the frame are replaced by
+// the next layer's pad value zc = max(zero,-128), which is exactly the reference's zero padding of
+// (q - zc).  HBM traffic per frame: the fp32 frame in (+ halo re-reads) and the int8
+// frame out -- ~15 % of the per-layer path's.
+//
+// Arithmetic, A-fragment packing and epilogues are those of sesrq_mfma.hip (same tables in
+// pack_mfma_frags, same reference citations); this file only re-plumbs where B operands come
+// from and where results go.
+#include <type_traits>
+
+#include "sesrq_mfma_common.h"
+
+namespace sesrq {
+
+constexpr int FW = 64;    // strip width (output pixels)
+constexpr int PA = 88;    // ring row pitch in pixels; column index c = u + 2
+constexpr int HT = 5;     // 16-pixel tiles per hidden row
+constexpr int DI = 8, D1 = 8, D2 = 4, D3 = 4, D4 = 8;   // ring depths (rows), powers of two
+constexpr int SUI = 23;   // input ring: 16-byte units per row per shifted copy (92 pixels)
+constexpr int INW = 89;   // input pixels per row: u = -2 .. 86
+
+__device__ __forceinline__ int slot(int r, int depth) { return (r + 64) & (depth - 1); }
+
+template <int MODE>
+__device__ __forceinline__ void sums(int s[4], const v4i *acc, const int4 ac) {
+    const int acv[4] = {ac.x, ac.y, ac.z, ac.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        if constexpr (MODE == MERGED) {
+            s[i] = acc[0][i];
+        } else {
+            const int t = clampi3(acc[0][i], -131072, 131071) + clampi3(acc[1][i], -131072, 131071) +
+                          clampi3(acc[2][i], -131072, 131071) + clampi3(acc[3][i], -131072, 131071);
+            s[i] = clampi3(t, -524288, 524287) + acv[i];
+        }
+    }
+}
+
+template <int M0, int MH, int M4>
+__global__ __launch_bounds__(256, 2) void fused5_kernel(const FusedArgs a) {
+    __shared__ int4 ring_in[DI * 4 * SUI];
+    __shared__ int4 ring1[D1 * PA], ring2[D2 * PA], ring3[D3 * PA], ring4[D4 * PA];
+    const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, n = l & 15, g = l >> 4;
+    const int x0 = blockIdx.x * FW, Y0 = blockIdx.y * a.chunk, n_img = blockIdx.z;
+    const int Y1 = min(Y0 + a.chunk, a.H);
+    const int H = a.H, W = a.W;
+    const size_t HW = (size_t)H * W;
+
+    // ---- weights: every wave keeps the A fragments of all five layers in registers
+    constexpr int NP0 = (M0 == MERGED) ? 1 : 4;
+    v4i A0[3][NP0];
+    v4i AH[3][MH == MERGED ? 3 : 4];
+    v4i A4[M4 == MERGED ? 10 : 8];
+    int4 ac0, acH[3], ac4;
+    {
+        const int4 *f0 = a.l[0].afrag;
+        ac0 = f0[g];
+#pragma unroll
+        for (int f = 0; f < 3; ++f)
+#pragma unroll
+            for (int p = 0; p < NP0; ++p) A0[f][p] = ld_frag(f0 + 4 + (f * NP0 + p) * 64 + l);
+#pragma unroll
+        for (int h = 0; h < 3; ++h) {
+            const int4 *fh = a.l[1 + h].afrag;
+            acH[h] = fh[g];
+#pragma unroll
+            for (int f = 0; f < (MH == MERGED ? 3 : 4); ++f) AH[h][f] = ld_frag(fh + 4 + f * 64 + l);
+        }
+        const int4 *f4 = a.l[4].afrag;
+        ac4 = f4[g];
+#pragma unroll
+        for (int f = 0; f < (M4 == MERGED ? 10 : 8); ++f) A4[f] = ld_frag(f4 + 4 + f * 64 + l);
+    }
+    const v4i zero4 = {0, 0, 0, 0};
+
+    // ---- frame input: element e = c * INW + v  (v = u + 2), one or two elements per thread
+    const size_t esz = 4;
+    const __amdgpu_buffer_rsrc_t rs_in =
+        __builtin_amdgcn_make_buffer_rsrc((char *)const_cast<void *>(a.in) + (size_t)n_img * a.ic * HW * esz, 0, (int)(a.ic * HW * esz), 0x00020000);
+    const int nel = a.ic * INW;
+    int e_c[2], e_v[2], e_x[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int e = tid + 256 * j;
+        e_c[j] = e / INW;
+        e_v[j] = e - e_c[j] * INW;
+        e_x[j] = x0 - 10 + e_v[j];
+    }
+    auto load_row = [&](int r, float out[2]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const bool ok = (tid + 256 * j < nel) & (r >= 0) & (r < H) & (e_x[j] >= 0) & (e_x[j] < W);
+            const int off = ok ? (int)((e_c[j] * (int)HW + r * W + e_x[j]) * esz) : (int)0x80000000;
+            out[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_in, off, 0, 0));
+        }
+    };
+    const int padb0 = a.pad_in0 & 0xff;
+    auto put_row = [&](int r, const float v[2]) __attribute__((always_inline)) {
+        signed char *ib = reinterpret_cast<signed char *>(ring_in);
+        const int sl = slot(r, DI);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            if (tid + 256 * j < nel) {
+                const bool ok = (r >= 0) & (r < H) & (e_x[j] >= 0) & (e_x[j] < W);
+                int q = (int)med3(rintf(__fadd_rn(__fdiv_rn(v[j], a.s_in), a.z_in)), -128.f, 127.f);
+                if (!ok) q = padb0;
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    const int t = e_v[j] - s;
+                    if (t >= 0) ib[((((sl * 4 + s) * SUI) + (t >> 2)) * 4 + (t & 3)) * 4 + e_c[j]] = (signed char)q;
+                }
+            }
+        }
+    };
+
+    // lane group -> (kernel row, 4-pixel segment) of the first layer's K-chunks (pack_mfma_frags, MFMA_F5)
+    const int f5_row[3] = {g, g == 0 ? 4 : g - 1, g == 0 ? 3 : (g == 1 ? 4 : 0)};
+    const int f5_seg[3] = {0, g == 0 ? 0 : 1, g < 2 ? 1 : 0};
+    // last layer, general: second K-chunk (row offset, column offset) per word
+    int l4_dr[4], l4_dc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        l4_dr[i] = (g == 0) ? 4 : (g == 1 ? i : 4);
+        l4_dc[i] = (g == 0) ? i : 4;
+    }
+    const float zlo[4] = {fmaxf(a.l[0].z_next, -128.f), fmaxf(a.l[1].z_next, -128.f), fmaxf(a.l[2].z_next, -128.f), -128.f};
+
+    // ------------------------------------------------------------------ tiles
+    auto tile_l0 = [&](int t, int r1) __attribute__((always_inline)) {
+        const int u0 = 16 * t;
+        v4i B[3];
+#pragma unroll
+        for (int f = 0; f < 3; ++f) {
+            const int c0 = u0 + n + 4 * f5_seg[f];
+            B[f] = ld_frag(ring_in + ((slot(r1 - 2 + f5_row[f], DI) * 4 + (c0 & 3)) * SUI + (c0 >> 2)));
+        }
+        v4i acc[NP0];
+        if constexpr (M0 == MERGED) {
+            const v4i c = {ac0.x, ac0.y, ac0.z, ac0.w};
+            acc[0] = mfma(A0[0][0], B[0], c);
+            acc[0] = mfma(A0[1][0], B[1], acc[0]);
+            acc[0] = mfma(A0[2][0], B[2], acc[0]);
+        } else {
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                acc[p] = mfma(A0[0][p], B[0], zero4);
+                acc[p] = mfma(A0[1][p], B[1], acc[p]);
+                acc[p] = mfma(A0[2][p], B[2], acc[p]);
+            }
+        }
+        int s[4];
+        sums<M0>(s, acc, ac0);
+        v2f v01, v23;
+        requant4<false>(s, a.l[0].Mf, a.l[0].sh, a.l[0].z_next, v01, v23);
+        unsigned word = round_pack(v01, v23, zlo[0], 127.f);
+        const int x = x0 - 8 + u0 + n;
+        if ((r1 < 0) | (r1 >= H) | (x < 0) | (x >= W)) word = (unsigned)a.l[0].pad_next;
+        reinterpret_cast<unsigned *>(ring1)[(slot(r1, D1) * PA + u0 + n + 2) * 4 + g] = word;
+    };
+
+    auto tile_h = [&](auto HL, int t, int r, const int4 *rin, int din, int4 *rout, int dout) __attribute__((always_inline)) {
+        constexpr int hl = decltype(HL)::value;          // 0,1,2 -> layers 1,2,3
+        const int u0 = 16 * t;
+        v4i acc[MH == MERGED ? 1 : 4];
+        if constexpr (MH == MERGED) {
+            const int c = u0 + n + 1 + g;
+            const v4i c0 = {acH[hl].x, acH[hl].y, acH[hl].z, acH[hl].w};
+            acc[0] = mfma(AH[hl][0], ld_frag(rin + slot(r - 1, din) * PA + c), c0);
+            acc[0] = mfma(AH[hl][1], ld_frag(rin + slot(r, din) * PA + c), acc[0]);
+            acc[0] = mfma(AH[hl][2], ld_frag(rin + slot(r + 1, din) * PA + c), acc[0]);
+        } else {
+            const int4 *row = rin + slot(r - 1 + g, din) * PA + u0 + n + 1;
+            const int4 P0 = row[0], P1 = row[1], P2 = row[2], P3 = row[3];
+            { const v4i b = {P0.x, P1.x, P2.x, P3.x}; acc[0] = mfma(AH[hl][0], b, zero4); }
+            { const v4i b = {P0.y, P1.y, P2.y, P3.y}; acc[1] = mfma(AH[hl][1], b, zero4); }
+            { const v4i b = {P0.z, P1.z, P2.z, P3.z}; acc[2] = mfma(AH[hl][2], b, zero4); }
+            { const v4i b = {P0.w, P1.w, P2.w, P3.w}; acc[3] = mfma(AH[hl][3], b, zero4); }
+        }
+        int s[4];
+        sums<MH>(s, acc, acH[hl]);
+        const FusedLayer &L = a.l[1 + hl];
+        unsigned word;
+        if constexpr (hl < 2) {
+            v2f v01, v23;
+            requant4<false>(s, L.Mf, L.sh, L.z_next, v01, v23);
+            word = round_pack(v01, v23, zlo[1 + hl], 127.f);
+        } else {
+            // layer 3: long residual merged in the integer domain (myQL/quan_func.py:249-270)
+            v2f v01, v23;
+            requant4<false>(s, L.Mf, L.sh, -128.f, v01, v23);
+            const unsigned rcw = reinterpret_cast<const unsigned *>(ring1)[(slot(r, D1) * PA + u0 + n + 2) * 4 + g];
+            const unsigned rcx = rcw ^ 0x80808080u;
+            const v2f k128 = {128.f, 128.f};
+            const v2f i01 = {rintf(med3(v01[0], -128.f, 127.f)), rintf(med3(v01[1], -128.f, 127.f))};
+            const v2f i23 = {rintf(med3(v23[0], -128.f, 127.f)), rintf(med3(v23[1], -128.f, 127.f))};
+            const v2f r01 = {(float)(rcx & 0xffu), (float)((rcx >> 8) & 0xffu)}, r23 = {(float)((rcx >> 16) & 0xffu), (float)(rcx >> 24)};
+            const v2f u01 = (r01 + k128) + i01, u23 = (r23 + k128) + i23;
+            const v2f M2 = {a.Mres, a.Mres}, sh2 = {a.shres, a.shres}, z2 = {a.z_merge, a.z_merge};
+            word = round_pack(__builtin_elementwise_fma(u01 * M2, sh2, z2), __builtin_elementwise_fma(u23 * M2, sh2, z2), -128.f, 127.f);
+        }
+        const int x = x0 - 8 + u0 + n;
+        if ((r < 0) | (r >= H) | (x < 0) | (x >= W)) word = (unsigned)L.pad_next;
+        reinterpret_cast<unsigned *>(rout)[(slot(r, dout) * PA + u0 + n + 2) * 4 + g] = word;
+    };
+
+    auto tile_l4 = [&](int t, int ro) __attribute__((always_inline)) {
+        const int u0 = 8 + 16 * t;
+        v4i acc[M4 == MERGED ? 1 : 4];
+        if constexpr (M4 == MERGED) {
+            const int c = u0 + n + g;
+            acc[0] = (v4i){ac4.x, ac4.y, ac4.z, ac4.w};
+#pragma unroll
+            for (int ky = 0; ky < 5; ++ky) {
+                const int4 *row = ring4 + slot(ro - 2 + ky, D4) * PA + c;
+                acc[0] = mfma(A4[ky * 2 + 0], ld_frag(row), acc[0]);
+                acc[0] = mfma(A4[ky * 2 + 1], ld_frag(row + 4), acc[0]);
+            }
+        } else {
+            {
+                const int4 *row = ring4 + slot(ro - 2 + g, D4) * PA + u0 + n;
+                const int4 P0 = row[0], P1 = row[1], P2 = row[2], P3 = row[3];
+                { const v4i b = {P0.x, P1.x, P2.x, P3.x}; acc[0] = mfma(A4[0], b, zero4); }
+                { const v4i b = {P0.y, P1.y, P2.y, P3.y}; acc[1] = mfma(A4[1], b, zero4); }
+                { const v4i b = {P0.z, P1.z, P2.z, P3.z}; acc[2] = mfma(A4[2], b, zero4); }
+                { const v4i b = {P0.w, P1.w, P2.w, P3.w}; acc[3] = mfma(A4[3], b, zero4); }
+            }
+            {
+                int4 P[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) P[i] = ring4[slot(ro - 2 + l4_dr[i], D4) * PA + u0 + n + l4_dc[i]];
+                { const v4i b = {P[0].x, P[1].x, P[2].x, P[3].x}; acc[0] = mfma(A4[4], b, acc[0]); }
+                { const v4i b = {P[0].y, P[1].y, P[2].y, P[3].y}; acc[1] = mfma(A4[5], b, acc[1]); }
+                { const v4i b = {P[0].z, P[1].z, P[2].z, P[3].z}; acc[2] = mfma(A4[6], b, acc[2]); }
+                { const v4i b = {P[0].w, P[1].w, P[2].w, P[3].w}; acc[3] = mfma(A4[7], b, acc[3]); }
+            }
+        }
+        int s[4];
+        sums<M4>(s, acc, ac4);
+        const int x = x0 + 16 * t + n;
+        if (x < W) {
+            v2f v01, v23;
+            requant4<false>(s, a.l[4].Mf, a.l[4].sh, a.z_out, v01, v23);
+            const float v[4] = {v01[0], v01[1], v23[0], v23[1]};
+            const int r = a.ps, r2 = r * r, Ho = H * r, Wo = W * r, cout = a.oc / r2;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int o = 4 * g + i;
+                if (o < a.oc) {
+                    const float q = rintf(med3(v[i], -128.f, 127.f));
+                    const int c = o / r2, rem = o - c * r2, ii = rem / r, jj = rem - ii * r;
+                    const size_t off = (((size_t)n_img * cout + c) * Ho + (size_t)ro * r + ii) * Wo + (size_t)x * r + jj;
+                    if (a.out_q) reinterpret_cast<signed char *>(a.out_q)[off] = (signed char)(int)q;
+                    if (a.out_f) a.out_f[off] = __fmul_rn(q - a.z_out, a.s_out);
+                }
+            }
+        }
+    };
+
+    // ------------------------------------------------------------------ row pipeline
+    float cur[2], nxt[2];
+    load_row(Y0 - 7, cur);
+    load_row(Y0 - 6, nxt);
+    const int steps = (Y1 - Y0) + 19;
+#pragma unroll 1
+    for (int s = 0; s < steps; ++s) {
+        const int rin = Y0 - 7 + s, r1 = rin - 3, r2 = r1 - 2, r3 = r2 - 2, r4 = r3 - 2, ro = r4 - 3;
+        if (rin < Y1 + 7) put_row(rin, cur);
+        cur[0] = nxt[0]; cur[1] = nxt[1];
+        load_row(rin + 2, nxt);
+        const bool act0 = (r1 >= Y0 - 5) & (r1 < Y1 + 5), act1 = (r2 >= Y0 - 4) & (r2 < Y1 + 4), act2 = (r3 >= Y0 - 3) & (r3 < Y1 + 3),
+                   act3 = (r4 >= Y0 - 2) & (r4 < Y1 + 2), act4 = (ro >= Y0) & (ro < Y1);
+#pragma unroll 1
+        for (int it = w; it < 24; it += 4) {
+            if (it < 4) { if (act4) tile_l4(it, ro); }
+            else if (it < 9) { if (act0) tile_l0(it - 4, r1); }
+            else if (it < 14) { if (act1) tile_h(std::integral_constant<int, 0>{}, it - 9, r2, ring1, D1, ring2, D2); }
+            else if (it < 19) { if (act2) tile_h(std::integral_constant<int, 1>{}, it - 14, r3, ring2, D2, ring3, D3); }
+            else { if (act3) tile_h(std::integral_constant<int, 2>{}, it - 19, r4, ring3, D3, ring4, D4); }
+        }
+        __syncthreads();
+    }
+}
+
+template <int M0, int MH, int M4>
+static void launch_fused_t(const FusedArgs &a, hipStream_t st) {
+    dim3 grid((a.W + FW - 1) / FW, (a.H + a.chunk - 1) / a.chunk, a.N);
+    hipLaunchKernelGGL((fused5_kernel<M0, MH, M4>), grid, dim3(256), 0, st, a);
+}
+
+int launch_fused5(const FusedArgs &a, bool gen0, bool genh, bool gen4, hipStream_t st) {
+    if ((size_t)a.H * a.W * a.ic * 4 >= ((size_t)1 << 31)) { set_error("fused: frame too large for 32-bit buffer offsets"); return 1; }
+    const int key = (gen0 ? 4 : 0) | (genh ? 2 : 0) | (gen4 ? 1 : 0);
+    switch (key) {
+        case 0: launch_fused_t<MERGED, MERGED, MERGED>(a, st); break;
+        case 1: launch_fused_t<MERGED, MERGED, GEN_STD>(a, st); break;
+        case 2: launch_fused_t<MERGED, GEN_STD, MERGED>(a, st); break;
+        case 3: launch_fused_t<MERGED, GEN_STD, GEN_STD>(a, st); break;
+        case 4: launch_fused_t<GEN_STD, MERGED, MERGED>(a, st); break;
+        case 5: launch_fused_t<GEN_STD, MERGED, GEN_STD>(a, st); break;
+        case 6: launch_fused_t<GEN_STD, GEN_STD, MERGED>(a, st); break;
+        default: launch_fused_t<GEN_STD, GEN_STD, GEN_STD>(a, st); break;
+    }
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { set_error(std::string("fused launch failed: ") + hipGetErrorString(e)); return 1; }
+    return 0;
+}
+
+}  // namespace sesrq

@@ -29,67 +29,32 @@
 //     monotone rounding commute with the clamp; fl(max(t,0)+z) == max(fl(t+z), z));
 //   * rint + float->int8 is one add of 1.5*2^23 (round-to-nearest-even into the low mantissa
 //     bits) followed by a byte pick; mul / fma / magic-add run as packed v_pk_*_f32.
-#include "sesrq_common.h"
+#include "sesrq_mfma_common.h"
 
 namespace sesrq {
 
-typedef int v4i __attribute__((ext_vector_type(4)));
-typedef unsigned v4u __attribute__((ext_vector_type(4)));
-typedef unsigned v2u __attribute__((ext_vector_type(2)));
-typedef float v2f __attribute__((ext_vector_type(2)));
-
 constexpr int MTW = 64;   // tile width : 4 waves x 16 pixels
 constexpr int MTH = 16;   // tile height: rows walked by every wave (multiple of 4)
-constexpr float MAGIC = 12582912.f;   // 1.5 * 2^23
-
-// accumulate modes
-enum { MERGED = 0, GEN_STD = 1, GEN_ANY = 2 };   // GEN_STD: 18/20-bit clamps as literals
-
-__device__ __forceinline__ v4i mfma(v4i a, v4i b, v4i c) { return __builtin_amdgcn_mfma_i32_16x16x64_i8(a, b, c, 0, 0, 0); }
-__device__ __forceinline__ float med3(float v, float lo, float hi) { return __builtin_amdgcn_fmed3f(v, lo, hi); }
-__device__ __forceinline__ int clampi3(int v, int lo, int hi) { return min(max(v, lo), hi); }
-__device__ __forceinline__ v4i ld_frag(const int4 *p) { const int4 t = *p; v4i r = {t.x, t.y, t.z, t.w}; return r; }
-__device__ __forceinline__ unsigned fbits(float f) { return __builtin_bit_cast(unsigned, f); }
-
-// low bytes of four words -> one word
-__device__ __forceinline__ unsigned pack_lo_bytes(unsigned y0, unsigned y1, unsigned y2, unsigned y3) {
-    const unsigned w01 = __builtin_amdgcn_perm(y1, y0, 0x0c0c0400u);
-    const unsigned w23 = __builtin_amdgcn_perm(y3, y2, 0x0c0c0400u);
-    return __builtin_amdgcn_perm(w23, w01, 0x05040100u);
-}
-
-// v[i] = fl(fl(s[i] * M) * 2^-n + zadd)   (un-rounded, two values per packed op)
-__device__ __forceinline__ void requant4(const int s[4], float Mf, float sh, float zadd, v2f &v01, v2f &v23) {
-    const v2f M2 = {Mf, Mf}, sh2 = {sh, sh}, z2 = {zadd, zadd};
-    const v2f f01 = {(float)s[0], (float)s[1]}, f23 = {(float)s[2], (float)s[3]};
-    v01 = __builtin_elementwise_fma(f01 * M2, sh2, z2);
-    v23 = __builtin_elementwise_fma(f23 * M2, sh2, z2);
-}
-
-// clamp (un-rounded) then round-half-even to int8, 4 values -> packed word
-__device__ __forceinline__ unsigned round_pack(v2f v01, v2f v23, float lo, float hi) {
-    const v2f mg = {MAGIC, MAGIC};
-    v2f c01 = {med3(v01[0], lo, hi), med3(v01[1], lo, hi)}, c23 = {med3(v23[0], lo, hi), med3(v23[1], lo, hi)};
-    c01 = c01 + mg; c23 = c23 + mg;
-    return pack_lo_bytes(fbits(c01[0]), fbits(c01[1]), fbits(c23[0]), fbits(c23[1]));
-}
 
 // hidden layer: q = clamp8(rint(relu(t) + z_next))            (myQL/quan_func.py:280)
+template <bool BIASED>
 __device__ __forceinline__ unsigned epi_mid(const int s[4], const ConvArgs &a, float zlo) {
     v2f v01, v23;
-    requant4(s, a.Mf, a.sh, a.z_next, v01, v23);
+    requant4<BIASED>(s, a.Mf, a.sh, a.z_next, v01, v23);
     return round_pack(v01, v23, zlo, 127.f);
 }
 // layer-0 residual operand rc = clamp8(rint(relu(t) - 128))    (myQL/quan_func.py:250)
+template <bool BIASED>
 __device__ __forceinline__ unsigned epi_rc(const int s[4], const ConvArgs &a) {
     v2f v01, v23;
-    requant4(s, a.Mf, a.sh, -128.f, v01, v23);
+    requant4<BIASED>(s, a.Mf, a.sh, -128.f, v01, v23);
     return round_pack(v01, v23, -128.f, 127.f);
 }
 // layer L-2: long residual merged in the integer domain        (myQL/quan_func.py:249-270)
+template <bool BIASED>
 __device__ __forceinline__ unsigned epi_preres(const int s[4], unsigned rcword, const ConvArgs &a) {
     v2f v01, v23;
-    requant4(s, a.Mf, a.sh, -128.f, v01, v23);
+    requant4<BIASED>(s, a.Mf, a.sh, -128.f, v01, v23);
     const unsigned rcx = rcword ^ 0x80808080u;                 // rc + 128 as unsigned bytes
     const v2f k128 = {128.f, 128.f};
     // ic = rint(clamp(t - 128)) ; u = rc + ic + 256 = (rc + 128) + ic + 128   (all exact small integers)
@@ -102,24 +67,57 @@ __device__ __forceinline__ unsigned epi_preres(const int s[4], unsigned rcword, 
     return round_pack(w01, w23, -128.f, 127.f);
 }
 
-// last layer: requantise into the output domain + PixelShuffle(r) store (int8 and/or fp32)
-__device__ __forceinline__ void epi_last(const int s[4], const ConvArgs &a, int g, int n, int gy, int gx, float zlo) {
-    const int r = a.ps, r2 = r * r, Ho = a.H * r, Wo = a.W * r, cout = a.oc / r2;
-    v2f v01, v23;
-    requant4(s, a.Mf, a.sh, a.z_out, v01, v23);
-    const float v[4] = {v01[0], v01[1], v23[0], v23[1]};
+// last layer: requantise into the output domain + PixelShuffle(r) store (int8 and/or fp32).
+// A lane owns output slots o = 4g..4g+3 of pixel (gy, gx); everything that depends only on the lane
+// (channel / sub-pixel decode, column offset, validity) is worked out once per kernel, a row adds one
+// scalar offset.  PixelShuffle(2) makes the 4 slots two 2-byte runs, PixelShuffle(4) one 4-byte run.
+struct LastStore {
+    __amdgpu_buffer_rsrc_t rq, rf;
+    int vo[4];            // element offset of slot i inside image n_img (out of range if invalid)
+    int r, row_elems;     // PixelShuffle factor, r * Wo
+    __device__ __forceinline__ void init(const ConvArgs &a, int n_img, int g, int gx) {
+        r = a.ps;
+        const int r2 = r * r, Ho = a.H * r, Wo = a.W * r, cout = a.oc / r2;
+        const size_t img = (size_t)cout * Ho * Wo;
+        rq = __builtin_amdgcn_make_buffer_rsrc((char *)a.out_q + (size_t)n_img * img, 0, a.out_q ? (int)img : 0, 0x00020000);
+        rf = __builtin_amdgcn_make_buffer_rsrc((char *)a.out_f + (size_t)n_img * img * 4, 0, a.out_f ? (int)(img * 4) : 0, 0x00020000);
+        row_elems = r * Wo;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int o = 4 * g + i;
-        if (o < a.oc) {
-            const float q = rintf(med3(v[i], zlo, 127.f));
+        for (int i = 0; i < 4; ++i) {
+            const int o = 4 * g + i;
             const int c = o / r2, rem = o - c * r2, ii = rem / r, jj = rem - ii * r;
-            const size_t off = (((size_t)n * cout + c) * Ho + (size_t)gy * r + ii) * Wo + (size_t)gx * r + jj;
-            if (a.out_q) reinterpret_cast<signed char *>(a.out_q)[off] = (signed char)(int)q;
-            if (a.out_f) a.out_f[off] = __fmul_rn(q - a.z_out, a.s_out);
+            vo[i] = (o < a.oc && gx < a.W) ? (c * Ho + ii) * Wo + gx * r + jj : (int)0x10000000;   // stays out of range times 4
         }
     }
-}
+    template <bool BIASED>
+    __device__ __forceinline__ void store(const int s[4], const ConvArgs &a, int gy, float zlo) const {
+        v2f v01, v23;
+        requant4<BIASED>(s, a.Mf, a.sh, a.z_out, v01, v23);
+        const v2f mg = {MAGIC, MAGIC};
+        v2f c01 = {med3(v01[0], zlo, 127.f), med3(v01[1], zlo, 127.f)}, c23 = {med3(v23[0], zlo, 127.f), med3(v23[1], zlo, 127.f)};
+        c01 = c01 + mg; c23 = c23 + mg;                    // low mantissa bits = rint(value), two's complement
+        const int so = gy * row_elems;
+        if (a.out_q) {
+            const unsigned w = pack_lo_bytes(fbits(c01[0]), fbits(c01[1]), fbits(c23[0]), fbits(c23[1]));
+            if (r == 2) {
+                __builtin_amdgcn_raw_buffer_store_b16((unsigned short)(w & 0xffffu), rq, vo[0], so, 0);
+                __builtin_amdgcn_raw_buffer_store_b16((unsigned short)(w >> 16), rq, vo[2], so, 0);
+            } else if (r == 4) {
+                __builtin_amdgcn_raw_buffer_store_b32(w, rq, vo[0], so, 0);
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) __builtin_amdgcn_raw_buffer_store_b8((unsigned char)((w >> (8 * i)) & 0xffu), rq, vo[i], so, 0);
+            }
+        }
+        if (a.out_f) {
+            const v2f q01 = c01 - mg, q23 = c23 - mg;      // exact: back to the integer-valued float
+            const float q[4] = {q01[0], q01[1], q23[0], q23[1]};
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                __builtin_amdgcn_raw_buffer_store_b32(fbits(__fmul_rn(q[i] - a.z_out, a.s_out)), rf, vo[i] * 4, so * 4, 0);
+        }
+    }
+};
 
 // PE clamp / sum / adder clamp / add constant               (myQL/quan_func.py:370,380-386,437,491)
 template <int MODE>
@@ -175,37 +173,107 @@ __device__ __forceinline__ void store_rows4(__amdgpu_buffer_rsrc_t rs, const Row
     __builtin_amdgcn_raw_buffer_store_b128(v, rs, io.voff, y4 * io.row_bytes, 0);
 }
 
-// stage a (SH x SW) window of NHWC16 pixels into LDS, pad word outside the frame.
-// All loads of a thread are issued back to back (buffer loads: out-of-range -> 0, then the pad
-// word is selected in), and only then written to LDS: one memory round trip per tile, not one
-// per loop iteration.
+// Staging of a (SH x SW) window of NHWC16 pixels, split in two phases so that a persistent
+// workgroup can keep the loads of its NEXT tile in flight while it computes the current one:
+//   load():  all buffer loads of a thread issued back to back (out-of-range -> 0)
+//   store(): pad word selected in for pixels outside the frame, then written to LDS
 template <int SH, int SW, int R>
-__device__ __forceinline__ void stage_nhwc16(int4 *tile, const ConvArgs &a, int n_img, int x0, int y0, int tid) {
-    constexpr int NIT = (SH * SW + 255) / 256;
-    const size_t img = (size_t)a.H * a.W * 16;
-    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((char *)const_cast<void *>(a.in) + (size_t)n_img * img, 0, (int)img, 0x00020000);
+struct StageNHWC16 {
+    static constexpr int NIT = (SH * SW + 255) / 256;
     v4u v[NIT];
     bool ok[NIT];
+    int voff[NIT], ty[NIT];      // per-lane byte offset of the pixel in tile row space; tile row of the pixel
+    __amdgpu_buffer_rsrc_t rs;
+    int row_bytes;
+    // Addresses are lane constants + ONE scalar per tile (soffset = y0 * W * 16): the loop issues its
+    // loads without touching a VGPR, so nothing forces a wait on the previous tile's stores.  Rows
+    // outside the frame fall out of the buffer's range check (gfx950 checks voffset + soffset).
+    __device__ __forceinline__ void init(const ConvArgs &a, int n_img, int x0, int tid) {
+        const size_t img = (size_t)a.H * a.W * 16;
+        rs = __builtin_amdgcn_make_buffer_rsrc((char *)const_cast<void *>(a.in) + (size_t)n_img * img, 0, (int)img, 0x00020000);
+        row_bytes = a.W * 16;
 #pragma unroll
-    for (int it = 0; it < NIT; ++it) {
-        const int i = tid + it * 256;
-        const int ty = i / SW, tx = i - ty * SW;
-        const int gy = y0 - R + ty, gx = x0 - R + tx;
-        ok[it] = (gy >= 0) & (gy < a.H) & (gx >= 0) & (gx < a.W) & (i < SH * SW);
-        v[it] = __builtin_amdgcn_raw_buffer_load_b128(rs, ok[it] ? (gy * a.W + gx) * 16 : (int)0x80000000, 0, 0);
+        for (int it = 0; it < NIT; ++it) {
+            const int i = tid + it * 256;
+            ty[it] = i / SW;
+            const int tx = i - ty[it] * SW, gx = x0 - R + tx;
+            const bool okx = (gx >= 0) & (gx < a.W) & (i < SH * SW);
+            voff[it] = okx ? (ty[it] * a.W + gx) * 16 : (int)0x80000000;
+            if (!okx) ty[it] = -(1 << 20);       // never a valid row -> pad
+        }
     }
-    const unsigned pw = (unsigned)a.pad_word;
+    // y0 >= R only (every tile but the first of the frame): offsets stay non-negative
+    __device__ __forceinline__ void load(const ConvArgs &a, int n_img, int x0, int y0, int tid) {
+        const int soff = (y0 - R) * row_bytes;
+        const int lo = R - y0, hi = a.H + R - y0;          // valid tile rows: lo <= ty < hi
 #pragma unroll
-    for (int it = 0; it < NIT; ++it) {
-        const int i = tid + it * 256;
-        const v4u pad = {pw, pw, pw, pw};
-        const v4u t = ok[it] ? v[it] : pad;
-        if (i < SH * SW) tile[i] = make_int4((int)t[0], (int)t[1], (int)t[2], (int)t[3]);
+        for (int it = 0; it < NIT; ++it) {
+            v[it] = __builtin_amdgcn_raw_buffer_load_b128(rs, voff[it], soff, 0);
+            ok[it] = (ty[it] >= lo) & (ty[it] < hi);
+        }
     }
-}
+    // any y0 (prologue of a chunk): per-lane offsets, rows above the frame pushed out of range
+    __device__ __forceinline__ void load_first(const ConvArgs &a, int n_img, int x0, int y0, int tid) {
+        const int lo = R - y0, hi = a.H + R - y0;
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            ok[it] = (ty[it] >= lo) & (ty[it] < hi);
+            v[it] = __builtin_amdgcn_raw_buffer_load_b128(rs, ok[it] ? voff[it] + (y0 - R) * row_bytes : (int)0x80000000, 0, 0);
+        }
+    }
+    __device__ __forceinline__ void store(int4 *tile, const ConvArgs &a, int tid) const {
+        const unsigned pw = (unsigned)a.pad_word;
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int i = tid + it * 256;
+            const v4u pad = {pw, pw, pw, pw};
+            const v4u t = ok[it] ? v[it] : pad;
+            if (i < SH * SW) tile[i] = make_int4((int)t[0], (int)t[1], (int)t[2], (int)t[3]);
+        }
+    }
+};
+
+// Persistent tile walk: a workgroup owns a 64-column strip and `a.chunk_tiles` vertically adjacent
+// 16-row tiles; tile k+1 is loaded (registers) while tile k is computed out of the other LDS buffer.
+// Diagnostic build only (-DSESRQ_STAMPS): wave 0 of every workgroup records s_memrealtime /
+// s_memtime at the phase boundaries into a buffer no other code reads (guide §7, in-kernel stamps).
+#ifdef SESRQ_STAMPS
+#define STAMP(k)                                                                                    \
+    if (a.dbg_pe && tid == 0) {                                                                     \
+        int *sp = a.dbg_pe + ((blockIdx.y * gridDim.x + blockIdx.x) * 16 + (k)) * 2;                \
+        sp[0] = (int)__builtin_amdgcn_s_memrealtime();                                              \
+        sp[1] = (int)__builtin_amdgcn_s_memtime();                                                  \
+    }
+#else
+#define STAMP(k)
+#endif
+#define SESRQ_TILE_WALK(STAGE_T, BUF0, BUF1, COMPUTE)                                              \
+    {                                                                                               \
+        const int t_begin = blockIdx.y * a.chunk_tiles;                                             \
+        const int t_end = min(t_begin + a.chunk_tiles, (a.H + MTH - 1) / MTH);                      \
+        STAGE_T st;                                                                                 \
+        st.init(a, n_img, x0, tid);                                                                 \
+        STAMP(0)                                                                                    \
+        st.load_first(a, n_img, x0, t_begin * MTH, tid);                                            \
+        STAMP(1)                                                                                    \
+        st.store(BUF0, a, tid);                                                                     \
+        __syncthreads();                                                                            \
+        STAMP(2)                                                                                    \
+        for (int t = t_begin; t < t_end; ++t) {                                                     \
+            const int y0 = t * MTH;                                                                 \
+            const bool cur0 = ((t - t_begin) & 1) == 0;                                             \
+            if (t + 1 < t_end) st.load(a, n_img, x0, y0 + MTH, tid);                                \
+            { const int4 *cur_tile = cur0 ? BUF0 : BUF1; COMPUTE(cur_tile) }                        \
+            STAMP(3 + 3 * (t - t_begin))                                                            \
+            if (t + 1 < t_end) { if (cur0) st.store(BUF1, a, tid); else st.store(BUF0, a, tid); }  \
+            STAMP(4 + 3 * (t - t_begin))                                                            \
+            __syncthreads();                                                                        \
+            STAMP(5 + 3 * (t - t_begin))                                                            \
+        }                                                                                           \
+    }
 
 // hidden-layer output of 4 rows: s4[r][i] -> requant -> transpose -> one 16-byte store per lane
-template <int EPI, bool RC>
+template <int EPI, bool RC, bool BIASED>
 __device__ __forceinline__ void emit_rows4(const int s4[4][4], const ConvArgs &a, const RowIO &io, int y4, float zlo) {
     unsigned w[4];
     if constexpr (EPI == EPI_PRERES) {
@@ -213,16 +281,16 @@ __device__ __forceinline__ void emit_rows4(const int s4[4][4], const ConvArgs &a
         unsigned rcw[4] = {rv[0], rv[1], rv[2], rv[3]};
         transpose4(rcw);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) w[r] = epi_preres(s4[r], rcw[r], a);
+        for (int r = 0; r < 4; ++r) w[r] = epi_preres<BIASED>(s4[r], rcw[r], a);
     } else {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) w[r] = epi_mid(s4[r], a, zlo);
+        for (int r = 0; r < 4; ++r) w[r] = epi_mid<BIASED>(s4[r], a, zlo);
     }
     store_rows4(io.out, io, y4, w);
     if constexpr (RC) {
         unsigned rw[4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) rw[r] = epi_rc(s4[r], a);
+        for (int r = 0; r < 4; ++r) rw[r] = epi_rc<BIASED>(s4[r], a);
         store_rows4(io.rc_out, io, y4, rw);
     }
 }
@@ -233,57 +301,64 @@ __global__ __launch_bounds__(256) void mfma_h3_kernel(const ConvArgs a) {
     constexpr bool GENERAL = MODE != MERGED;
     constexpr int SW = MTW + 4;                      // 1 left halo + 64 + 1 right halo + over-read
     constexpr int SH = MTH + 2 + (GENERAL ? 1 : 0);  // general reads row y+3 with zero weights
-    __shared__ int4 tile[SH * SW];
+    __shared__ int4 buf0[SH * SW], buf1[SH * SW];
     const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, n = l & 15, g = l >> 4;
-    const int x0 = blockIdx.x * MTW, y0 = blockIdx.y * MTH, n_img = blockIdx.z;
-    stage_nhwc16<SH, SW, 1>(tile, a, n_img, x0, y0, tid);
+    const int x0 = blockIdx.x * MTW, n_img = blockIdx.z;
     const int4 *fr = a.afrag;
-    const int4 ac = fr[g];
+    constexpr bool BIASED = MODE != GEN_ANY;     // requant without v_cvt: sums carry + MAGIC_I (needs |s| < 2^22)
+    int4 ac = fr[g];
+    if constexpr (BIASED) { ac.x += MAGIC_I; ac.y += MAGIC_I; ac.z += MAGIC_I; ac.w += MAGIC_I; }
     v4i A[GENERAL ? 4 : 3];
 #pragma unroll
     for (int f = 0; f < (GENERAL ? 4 : 3); ++f) A[f] = ld_frag(fr + 4 + f * 64 + l);
     const float zlo = a.relu ? fmaxf(a.z_next, -128.f) : -128.f;
-    const RowIO io = make_rowio(a, n_img, y0, x0 + 16 * w + n, g);
-    __syncthreads();
-    if constexpr (!GENERAL) {
-        const int col = 16 * w + n + g;
-        const v4i acc0 = {ac.x, ac.y, ac.z, ac.w};
-        v4i B0 = ld_frag(tile + col), B1 = ld_frag(tile + SW + col);
+    const int gx = x0 + 16 * w + n;
+    auto compute = [&](const int4 *tile, int y0) __attribute__((always_inline)) {
+        const RowIO io = make_rowio(a, n_img, y0, gx, g);
+        if constexpr (!GENERAL) {
+            const int col = 16 * w + n + g;
+            const v4i acc0 = {ac.x, ac.y, ac.z, ac.w};
+            v4i B0 = ld_frag(tile + col), B1 = ld_frag(tile + SW + col);
 #pragma unroll
-        for (int y4 = 0; y4 < MTH; y4 += 4) {
-            int s4[4][4];
+            for (int y4 = 0; y4 < MTH; y4 += 4) {
+                int s4[4][4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const v4i B2 = ld_frag(tile + (y4 + r + 2) * SW + col);
-                v4i acc[1];
-                acc[0] = mfma(A[0], B0, acc0);
-                acc[0] = mfma(A[1], B1, acc[0]);
-                acc[0] = mfma(A[2], B2, acc[0]);
-                B0 = B1; B1 = B2;
-                finish_sums<MERGED>(s4[r], acc, ac, a);
+                for (int r = 0; r < 4; ++r) {
+                    const v4i B2 = ld_frag(tile + (y4 + r + 2) * SW + col);
+                    v4i acc[1];
+                    acc[0] = mfma(A[0], B0, acc0);
+                    acc[0] = mfma(A[1], B1, acc[0]);
+                    acc[0] = mfma(A[2], B2, acc[0]);
+                    B0 = B1; B1 = B2;
+                    finish_sums<MERGED>(s4[r], acc, ac, a);
+                }
+                emit_rows4<EPI, false, BIASED>(s4, a, io, y4, zlo);
             }
-            emit_rows4<EPI, false>(s4, a, io, y4, zlo);
-        }
-    } else {
-        const int col = 16 * w + n;
+        } else {
+            const int col = 16 * w + n;
 #pragma unroll 1
-        for (int y4 = 0; y4 < MTH; y4 += 4) {
-            int s4[4][4];
+            for (int y4 = 0; y4 < MTH; y4 += 4) {
+                int s4[4][4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int4 *row = tile + (y4 + r + g) * SW + col;     // lane group g = kernel row ky
-                const int4 P0 = row[0], P1 = row[1], P2 = row[2], P3 = row[3];
-                const v4i zero = {0, 0, 0, 0};
-                v4i acc[4];
-                { const v4i b = {P0.x, P1.x, P2.x, P3.x}; acc[0] = mfma(A[0], b, zero); }
-                { const v4i b = {P0.y, P1.y, P2.y, P3.y}; acc[1] = mfma(A[1], b, zero); }
-                { const v4i b = {P0.z, P1.z, P2.z, P3.z}; acc[2] = mfma(A[2], b, zero); }
-                { const v4i b = {P0.w, P1.w, P2.w, P3.w}; acc[3] = mfma(A[3], b, zero); }
-                finish_sums<MODE>(s4[r], acc, ac, a);
+                for (int r = 0; r < 4; ++r) {
+                    const int4 *row = tile + (y4 + r + g) * SW + col;     // lane group g = kernel row ky
+                    const int4 P0 = row[0], P1 = row[1], P2 = row[2], P3 = row[3];
+                    const v4i zero = {0, 0, 0, 0};
+                    v4i acc[4];
+                    { const v4i b = {P0.x, P1.x, P2.x, P3.x}; acc[0] = mfma(A[0], b, zero); }
+                    { const v4i b = {P0.y, P1.y, P2.y, P3.y}; acc[1] = mfma(A[1], b, zero); }
+                    { const v4i b = {P0.z, P1.z, P2.z, P3.z}; acc[2] = mfma(A[2], b, zero); }
+                    { const v4i b = {P0.w, P1.w, P2.w, P3.w}; acc[3] = mfma(A[3], b, zero); }
+                    finish_sums<MODE>(s4[r], acc, ac, a);
+                }
+                emit_rows4<EPI, false, BIASED>(s4, a, io, y4, zlo);
             }
-            emit_rows4<EPI, false>(s4, a, io, y4, zlo);
         }
-    }
+    };
+#define SESRQ_COMPUTE(B) compute(B, y0);
+    using Stage = StageNHWC16<SH, SW, 1>;
+    SESRQ_TILE_WALK(Stage, buf0, buf1, SESRQ_COMPUTE)
+#undef SESRQ_COMPUTE
 }
 
 // ------------------------------------------------------------------ 5x5, 16 input channels
@@ -292,99 +367,100 @@ __global__ __launch_bounds__(256) void mfma_h5_kernel(const ConvArgs a) {
     constexpr bool GENERAL = MODE != MERGED;
     constexpr int SW = MTW + 8;          // 2 + 64 + 2 halo, + over-read of the kx = 4..7 group
     constexpr int SH = MTH + 4;
-    __shared__ int4 tile[SH * SW];
+    __shared__ int4 buf0[SH * SW], buf1[SH * SW];
     const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, n = l & 15, g = l >> 4;
-    const int x0 = blockIdx.x * MTW, y0 = blockIdx.y * MTH, n_img = blockIdx.z;
-    stage_nhwc16<SH, SW, 2>(tile, a, n_img, x0, y0, tid);
+    const int x0 = blockIdx.x * MTW, n_img = blockIdx.z;
     const int4 *fr = a.afrag;
-    const int4 ac = fr[g];
+    constexpr bool BIASED = MODE != GEN_ANY;     // requant without v_cvt: sums carry + MAGIC_I (needs |s| < 2^22)
+    int4 ac = fr[g];
+    if constexpr (BIASED) { ac.x += MAGIC_I; ac.y += MAGIC_I; ac.z += MAGIC_I; ac.w += MAGIC_I; }
     const float zlo = a.relu ? fmaxf(EPI == EPI_LAST ? a.z_out : a.z_next, -128.f) : -128.f;
     const int gx = x0 + 16 * w + n;
-    RowIO io;
-    if constexpr (EPI != EPI_LAST) io = make_rowio(a, n_img, y0, gx, g);
-    if constexpr (!GENERAL) {
-        // frag (ky, h): lane group g = tap kx = 4h + g  (h = 1: only kx = 4 carries weights)
-        v4i A[5][2];
+    // merged: frag (ky, h): lane group g = tap kx = 4h + g  (h = 1: only kx = 4 carries weights)
+    // general, per PE p two K-chunks:  f = 0: group g = ky 0..3, words = kx 0..3
+    //                                  f = 1: g0 = (ky 4, kx 0..3)  g1 = (ky 0..3, kx 4)  g2 = (4,4)  g3 = none
+    constexpr int NF = GENERAL ? 8 : 10;
+    v4i A[NF];
 #pragma unroll
-        for (int ky = 0; ky < 5; ++ky)
+    for (int f = 0; f < NF; ++f) A[f] = ld_frag(fr + 4 + f * 64 + l);
+    int off1[4];
 #pragma unroll
-            for (int h = 0; h < 2; ++h) A[ky][h] = ld_frag(fr + 4 + (ky * 2 + h) * 64 + l);
-        __syncthreads();
-        const int col = 16 * w + n + g;
-        const v4i acc0 = {ac.x, ac.y, ac.z, ac.w};
-        v4i B[5][2];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            B[r][0] = ld_frag(tile + r * SW + col);
-            B[r][1] = ld_frag(tile + r * SW + col + 4);
-        }
-#pragma unroll
-        for (int y4 = 0; y4 < MTH; y4 += 4) {
-            int s4[4][4];
+    for (int i = 0; i < 4; ++i) off1[i] = (g == 0) ? 4 * SW + i : (g == 1 ? i * SW + 4 : 4 * SW + 4);
+    LastStore ls;
+    if constexpr (EPI == EPI_LAST) ls.init(a, n_img, g, gx);
+    auto compute = [&](const int4 *tile, int y0) __attribute__((always_inline)) {
+        RowIO io;
+        if constexpr (EPI != EPI_LAST) io = make_rowio(a, n_img, y0, gx, g);
+        if constexpr (!GENERAL) {
+            const int col = 16 * w + n + g;
+            const v4i acc0 = {ac.x, ac.y, ac.z, ac.w};
+            v4i B[5][2];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int y = y4 + r;
-                B[(y + 4) % 5][0] = ld_frag(tile + (y + 4) * SW + col);
-                B[(y + 4) % 5][1] = ld_frag(tile + (y + 4) * SW + col + 4);
-                v4i acc[1];
-                acc[0] = acc0;
-#pragma unroll
-                for (int ky = 0; ky < 5; ++ky) {
-                    acc[0] = mfma(A[ky][0], B[(y + ky) % 5][0], acc[0]);
-                    acc[0] = mfma(A[ky][1], B[(y + ky) % 5][1], acc[0]);
-                }
-                finish_sums<MERGED>(s4[r], acc, ac, a);
-                if constexpr (EPI == EPI_LAST) {
-                    if (y0 + y < a.H && gx < a.W) epi_last(s4[r], a, g, n_img, y0 + y, gx, zlo);
-                }
+                B[r][0] = ld_frag(tile + r * SW + col);
+                B[r][1] = ld_frag(tile + r * SW + col + 4);
             }
-            if constexpr (EPI != EPI_LAST) emit_rows4<EPI, false>(s4, a, io, y4, zlo);
-        }
-    } else {
-        // per PE p two K-chunks:  f = 0: group g = ky 0..3, words = kx 0..3
-        //                         f = 1: g0 = (ky 4, kx 0..3)  g1 = (ky 0..3, kx 4)  g2 = (4,4)  g3 = none
-        v4i A[2][4];
 #pragma unroll
-        for (int f = 0; f < 2; ++f)
+            for (int y4 = 0; y4 < MTH; y4 += 4) {
+                int s4[4][4];
 #pragma unroll
-            for (int p = 0; p < 4; ++p) A[f][p] = ld_frag(fr + 4 + (f * 4 + p) * 64 + l);
-        __syncthreads();
-        const int col = 16 * w + n;
-        int off1[4];
+                for (int r = 0; r < 4; ++r) {
+                    const int y = y4 + r;
+                    B[(y + 4) % 5][0] = ld_frag(tile + (y + 4) * SW + col);
+                    B[(y + 4) % 5][1] = ld_frag(tile + (y + 4) * SW + col + 4);
+                    v4i acc[1];
+                    acc[0] = acc0;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) off1[i] = (g == 0) ? 4 * SW + i : (g == 1 ? i * SW + 4 : 4 * SW + 4);
+                    for (int ky = 0; ky < 5; ++ky) {
+                        acc[0] = mfma(A[ky * 2 + 0], B[(y + ky) % 5][0], acc[0]);
+                        acc[0] = mfma(A[ky * 2 + 1], B[(y + ky) % 5][1], acc[0]);
+                    }
+                    finish_sums<MERGED>(s4[r], acc, ac, a);
+                    if constexpr (EPI == EPI_LAST) {
+                        if (y0 + y < a.H) ls.store<BIASED>(s4[r], a, y0 + y, zlo);
+                    }
+                }
+                if constexpr (EPI != EPI_LAST) emit_rows4<EPI, false, BIASED>(s4, a, io, y4, zlo);
+            }
+        } else {
+            const int col = 16 * w + n;
 #pragma unroll 1
-        for (int y4 = 0; y4 < MTH; y4 += 4) {
-            int s4[4][4];
+            for (int y4 = 0; y4 < MTH; y4 += 4) {
+                int s4[4][4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int y = y4 + r;
-                const v4i zero = {0, 0, 0, 0};
-                v4i acc[4];
-                {
-                    const int4 *row = tile + (y + g) * SW + col;
-                    const int4 P0 = row[0], P1 = row[1], P2 = row[2], P3 = row[3];
-                    { const v4i b = {P0.x, P1.x, P2.x, P3.x}; acc[0] = mfma(A[0][0], b, zero); }
-                    { const v4i b = {P0.y, P1.y, P2.y, P3.y}; acc[1] = mfma(A[0][1], b, zero); }
-                    { const v4i b = {P0.z, P1.z, P2.z, P3.z}; acc[2] = mfma(A[0][2], b, zero); }
-                    { const v4i b = {P0.w, P1.w, P2.w, P3.w}; acc[3] = mfma(A[0][3], b, zero); }
+                for (int r = 0; r < 4; ++r) {
+                    const int y = y4 + r;
+                    const v4i zero = {0, 0, 0, 0};
+                    v4i acc[4];
+                    {
+                        const int4 *row = tile + (y + g) * SW + col;
+                        const int4 P0 = row[0], P1 = row[1], P2 = row[2], P3 = row[3];
+                        { const v4i b = {P0.x, P1.x, P2.x, P3.x}; acc[0] = mfma(A[0], b, zero); }
+                        { const v4i b = {P0.y, P1.y, P2.y, P3.y}; acc[1] = mfma(A[1], b, zero); }
+                        { const v4i b = {P0.z, P1.z, P2.z, P3.z}; acc[2] = mfma(A[2], b, zero); }
+                        { const v4i b = {P0.w, P1.w, P2.w, P3.w}; acc[3] = mfma(A[3], b, zero); }
+                    }
+                    {
+                        const int4 *base = tile + y * SW + col;
+                        const int4 P0 = base[off1[0]], P1 = base[off1[1]], P2 = base[off1[2]], P3 = base[off1[3]];
+                        { const v4i b = {P0.x, P1.x, P2.x, P3.x}; acc[0] = mfma(A[4], b, acc[0]); }
+                        { const v4i b = {P0.y, P1.y, P2.y, P3.y}; acc[1] = mfma(A[5], b, acc[1]); }
+                        { const v4i b = {P0.z, P1.z, P2.z, P3.z}; acc[2] = mfma(A[6], b, acc[2]); }
+                        { const v4i b = {P0.w, P1.w, P2.w, P3.w}; acc[3] = mfma(A[7], b, acc[3]); }
+                    }
+                    finish_sums<MODE>(s4[r], acc, ac, a);
+                    if constexpr (EPI == EPI_LAST) {
+                        if (y0 + y < a.H) ls.store<BIASED>(s4[r], a, y0 + y, zlo);
+                    }
                 }
-                {
-                    const int4 *base = tile + y * SW + col;
-                    const int4 P0 = base[off1[0]], P1 = base[off1[1]], P2 = base[off1[2]], P3 = base[off1[3]];
-                    { const v4i b = {P0.x, P1.x, P2.x, P3.x}; acc[0] = mfma(A[1][0], b, acc[0]); }
-                    { const v4i b = {P0.y, P1.y, P2.y, P3.y}; acc[1] = mfma(A[1][1], b, acc[1]); }
-                    { const v4i b = {P0.z, P1.z, P2.z, P3.z}; acc[2] = mfma(A[1][2], b, acc[2]); }
-                    { const v4i b = {P0.w, P1.w, P2.w, P3.w}; acc[3] = mfma(A[1][3], b, acc[3]); }
-                }
-                finish_sums<MODE>(s4[r], acc, ac, a);
-                if constexpr (EPI == EPI_LAST) {
-                    if (y0 + y < a.H && gx < a.W) epi_last(s4[r], a, g, n_img, y0 + y, gx, zlo);
-                }
+                if constexpr (EPI != EPI_LAST) emit_rows4<EPI, false, BIASED>(s4, a, io, y4, zlo);
             }
-            if constexpr (EPI != EPI_LAST) emit_rows4<EPI, false>(s4, a, io, y4, zlo);
         }
-    }
+    };
+#define SESRQ_COMPUTE(B) compute(B, y0);
+    using Stage = StageNHWC16<SH, SW, 2>;
+    SESRQ_TILE_WALK(Stage, buf0, buf1, SESRQ_COMPUTE)
+#undef SESRQ_COMPUTE
 }
 
 // ------------------------------------------------------------------ first layer 5x5, IC <= 4
@@ -392,38 +468,53 @@ __global__ __launch_bounds__(256) void mfma_h5_kernel(const ConvArgs a) {
 // a pixel is one dword (byte c = channel c).  A lane's 16 bytes = 4 horizontally adjacent
 // pixels, which start at an arbitrary pixel column -> the tile is kept in 4 copies shifted by
 // 0..3 pixels so that every such group is one aligned ds_read_b128.
-template <int MODE, int SRC, bool RC>
-__global__ __launch_bounds__(256) void mfma_f5_kernel(const ConvArgs a) {
-    constexpr bool GENERAL = MODE != MERGED;
-    constexpr int SH = MTH + 4;
-    constexpr int SWP = MTW + 8;         // staged pixel columns (2 halo + 64 + 2 halo + over-read)
-    constexpr int SU = SWP / 4;          // 16-byte units per row per copy
-    __shared__ int4 cp[4 * SH * SU];
-    const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, n = l & 15, g = l >> 4;
-    const int x0 = blockIdx.x * MTW, y0 = blockIdx.y * MTH, n_img = blockIdx.z;
-    const size_t HW = (size_t)a.H * a.W;
-    int *cpw = reinterpret_cast<int *>(cp);
-    {
-        // all frame loads of a thread first (buffer loads, out-of-range -> 0), then quantise + LDS writes
-        constexpr int NIT = (SH * SWP + 255) / 256;
-        const size_t esz = (SRC == SRC_F32) ? 4 : 1;
-        const size_t img = HW * a.ic * esz;
-        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((char *)const_cast<void *>(a.in) + (size_t)n_img * img, 0, (int)img, 0x00020000);
-        unsigned raw[NIT][4];
-        bool ok[NIT];
+template <int SRC, int SH, int SWP>
+struct StageFrame {
+    static constexpr int NIT = (SH * SWP + 255) / 256;
+    static constexpr int SU = SWP / 4;
+    static constexpr int ESZ = (SRC == SRC_F32) ? 4 : 1;
+    unsigned raw[NIT][4];
+    bool ok[NIT];
+    int voff[NIT], ty[NIT];
+    __amdgpu_buffer_rsrc_t rs;
+    int row_bytes, plane_bytes;
+    __device__ __forceinline__ void init(const ConvArgs &a, int n_img, int x0, int tid) {
+        const size_t HW = (size_t)a.H * a.W;
+        const size_t img = HW * a.ic * ESZ;
+        rs = __builtin_amdgcn_make_buffer_rsrc((char *)const_cast<void *>(a.in) + (size_t)n_img * img, 0, (int)img, 0x00020000);
+        row_bytes = a.W * ESZ;
+        plane_bytes = (int)(HW * ESZ);
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
             const int i = tid + it * 256;
-            const int ty = i / SWP, tx = i - ty * SWP;
-            const int gy = y0 - 2 + ty, gx = x0 - 2 + tx;
-            ok[it] = (gy >= 0) & (gy < a.H) & (gx >= 0) & (gx < a.W) & (i < SH * SWP);
+            ty[it] = i / SWP;
+            const int tx = i - ty[it] * SWP, gx = x0 - 2 + tx;
+            const bool okx = (gx >= 0) & (gx < a.W) & (i < SH * SWP);
+            voff[it] = okx ? (ty[it] * a.W + gx) * ESZ : (int)0x80000000;
+            if (!okx) ty[it] = -(1 << 20);
+        }
+    }
+    template <bool FIRST>
+    __device__ __forceinline__ void load_t(const ConvArgs &a, int y0) {
+        const int soff = (y0 - 2) * row_bytes;             // FIRST: may be negative -> folded into the lane offset
+        const int lo = 2 - y0, hi = a.H + 2 - y0;
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            ok[it] = (ty[it] >= lo) & (ty[it] < hi);
+            const int vo = FIRST ? (ok[it] ? voff[it] + soff : (int)0x80000000) : voff[it];
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
-                const int off = (ok[it] && c < a.ic) ? (int)((c * (int)HW + gy * a.W + gx) * esz) : (int)0x80000000;
-                if constexpr (SRC == SRC_F32) raw[it][c] = __builtin_amdgcn_raw_buffer_load_b32(rs, off, 0, 0);
-                else raw[it][c] = (unsigned)(int)(signed char)__builtin_amdgcn_raw_buffer_load_b8(rs, off, 0, 0);
+                // channel planes beyond ic: the whole load is pushed out of range (returns 0, masked below)
+                const int so = (c < a.ic) ? (FIRST ? 0 : soff) + c * plane_bytes : (int)0x7fffff00;
+                if constexpr (SRC == SRC_F32) raw[it][c] = __builtin_amdgcn_raw_buffer_load_b32(rs, vo, so, 0);
+                else raw[it][c] = (unsigned)(int)(signed char)__builtin_amdgcn_raw_buffer_load_b8(rs, vo, so, 0);
             }
         }
+    }
+    __device__ __forceinline__ void load(const ConvArgs &a, int n_img, int x0, int y0, int tid) { load_t<false>(a, y0); }
+    __device__ __forceinline__ void load_first(const ConvArgs &a, int n_img, int x0, int y0, int tid) { load_t<true>(a, y0); }
+    __device__ __forceinline__ void store(int4 *cp, const ConvArgs &a, int tid) const {
+        int *cpw = reinterpret_cast<int *>(cp);
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
             const int i = tid + it * 256;
@@ -448,8 +539,22 @@ __global__ __launch_bounds__(256) void mfma_f5_kernel(const ConvArgs a) {
             }
         }
     }
+};
+
+template <int MODE, int SRC, bool RC>
+__global__ __launch_bounds__(256) void mfma_f5_kernel(const ConvArgs a) {
+    constexpr bool GENERAL = MODE != MERGED;
+    constexpr int SH = MTH + 4;
+    constexpr int SWP = MTW + 8;         // staged pixel columns (2 halo + 64 + 2 halo + over-read)
+    constexpr int SU = SWP / 4;          // 16-byte units per row per copy
+    __shared__ int4 buf0[4 * SH * SU], buf1[4 * SH * SU];
+    const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, n = l & 15, g = l >> 4;
+    const int x0 = blockIdx.x * MTW, n_img = blockIdx.z;
+    const size_t HW = (size_t)a.H * a.W;
     const int4 *fr = a.afrag;
-    const int4 ac = fr[g];
+    constexpr bool BIASED = MODE != GEN_ANY;     // requant without v_cvt: sums carry + MAGIC_I (needs |s| < 2^22)
+    int4 ac = fr[g];
+    if constexpr (BIASED) { ac.x += MAGIC_I; ac.y += MAGIC_I; ac.z += MAGIC_I; ac.w += MAGIC_I; }
     constexpr int NPE = GENERAL ? 4 : 1;
     v4i A[3][NPE];
 #pragma unroll
@@ -470,44 +575,57 @@ __global__ __launch_bounds__(256) void mfma_f5_kernel(const ConvArgs a) {
     }
     const float zlo = a.relu ? fmaxf(a.z_next, -128.f) : -128.f;
     const int gx = x0 + 16 * w + n;
-    const RowIO io = make_rowio(a, n_img, y0, gx, g);
-    __syncthreads();
+    auto compute = [&](const int4 *cp, int y0) __attribute__((always_inline)) {
+        const RowIO io = make_rowio(a, n_img, y0, gx, g);
+        const int *cpw = reinterpret_cast<const int *>(cp);
 #pragma unroll 1
-    for (int y4 = 0; y4 < MTH; y4 += 4) {
-        int s4[4][4];
+        for (int y4 = 0; y4 < MTH; y4 += 4) {
+            int s4[4][4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int y = y4 + r;
-            const v4i B0 = ld_frag(cp + addr[0] + y * SU), B1 = ld_frag(cp + addr[1] + y * SU), B2 = ld_frag(cp + addr[2] + y * SU);
-            v4i acc[GENERAL ? 4 : 1];
-            if constexpr (GENERAL) {
-                const v4i zero = {0, 0, 0, 0};
+            for (int r = 0; r < 4; ++r) {
+                const int y = y4 + r;
+                const v4i B0 = ld_frag(cp + addr[0] + y * SU), B1 = ld_frag(cp + addr[1] + y * SU), B2 = ld_frag(cp + addr[2] + y * SU);
+                v4i acc[GENERAL ? 4 : 1];
+                if constexpr (GENERAL) {
+                    const v4i zero = {0, 0, 0, 0};
 #pragma unroll
-                for (int p = 0; p < 4; ++p) {
-                    acc[p] = mfma(A[0][p], B0, zero);
-                    acc[p] = mfma(A[1][p], B1, acc[p]);
-                    acc[p] = mfma(A[2][p], B2, acc[p]);
+                    for (int p = 0; p < 4; ++p) {
+                        acc[p] = mfma(A[0][p], B0, zero);
+                        acc[p] = mfma(A[1][p], B1, acc[p]);
+                        acc[p] = mfma(A[2][p], B2, acc[p]);
+                    }
+                } else {
+                    const v4i acc0 = {ac.x, ac.y, ac.z, ac.w};
+                    acc[0] = mfma(A[0][0], B0, acc0);
+                    acc[0] = mfma(A[1][0], B1, acc[0]);
+                    acc[0] = mfma(A[2][0], B2, acc[0]);
                 }
-            } else {
-                const v4i acc0 = {ac.x, ac.y, ac.z, ac.w};
-                acc[0] = mfma(A[0][0], B0, acc0);
-                acc[0] = mfma(A[1][0], B1, acc[0]);
-                acc[0] = mfma(A[2][0], B2, acc[0]);
+                finish_sums<MODE>(s4[r], acc, ac, a);
+                if (a.dbg_q0 && g == 0 && y0 + y < a.H && gx < a.W) {
+                    const int word = cpw[((0 * SH + y + 2) * SU + ((16 * w + n + 2) >> 2)) * 4 + ((16 * w + n + 2) & 3)];
+                    for (int c = 0; c < a.ic; ++c)
+                        a.dbg_q0[((size_t)n_img * a.ic + c) * HW + (size_t)(y0 + y) * a.W + gx] = (signed char)((word >> (8 * c)) & 0xff);
+                }
             }
-            finish_sums<MODE>(s4[r], acc, ac, a);
-            if (a.dbg_q0 && g == 0 && y0 + y < a.H && gx < a.W) {
-                const int word = cpw[((0 * SH + y + 2) * SU + ((16 * w + n + 2) >> 2)) * 4 + ((16 * w + n + 2) & 3)];
-                for (int c = 0; c < a.ic; ++c)
-                    a.dbg_q0[((size_t)n_img * a.ic + c) * HW + (size_t)(y0 + y) * a.W + gx] = (signed char)((word >> (8 * c)) & 0xff);
-            }
+            emit_rows4<EPI_MID, RC, BIASED>(s4, a, io, y4, zlo);
         }
-        emit_rows4<EPI_MID, RC>(s4, a, io, y4, zlo);
-    }
+    };
+#define SESRQ_COMPUTE(B) compute(B, y0);
+    using Stage = StageFrame<SRC, SH, SWP>;
+    SESRQ_TILE_WALK(Stage, buf0, buf1, SESRQ_COMPUTE)
+#undef SESRQ_COMPUTE
 }
 
+#ifdef SESRQ_STAMPS
+static int *g_stampbuf = nullptr;
+extern "C" int sesrq_debug_fetch_stamps(void *host, size_t bytes) {
+    return g_stampbuf ? (int)hipMemcpy(host, g_stampbuf, bytes, hipMemcpyDeviceToHost) : -1;
+}
+#endif
 template <typename K>
 static void launch(K kern, const ConvArgs &a, hipStream_t st) {
-    dim3 grid((a.W + MTW - 1) / MTW, (a.H + MTH - 1) / MTH, a.N);
+    const int row_tiles = (a.H + MTH - 1) / MTH;
+    dim3 grid((a.W + MTW - 1) / MTW, (row_tiles + a.chunk_tiles - 1) / a.chunk_tiles, a.N);
     hipLaunchKernelGGL(kern, grid, dim3(256), 0, st, a);
 }
 
@@ -518,8 +636,19 @@ static void launch(K kern, const ConvArgs &a, hipStream_t st) {
         else launch(KERN<GEN_ANY, __VA_ARGS__>, a, st);                                  \
     } while (0)
 
-int launch_mfma(const LayerPlan &lp, const ConvArgs &a, int src, int epi, bool general, hipStream_t st) {
-    if ((size_t)a.H * a.W * 16 >= ((size_t)1 << 31)) { set_error("mfma: frame too large for 32-bit buffer offsets"); return 1; }
+int launch_mfma(const LayerPlan &lp, const ConvArgs &a_in, int src, int epi, bool general, hipStream_t st) {
+    ConvArgs a = a_in;
+#ifdef SESRQ_STAMPS
+    if (!g_stampbuf) { (void)hipMalloc((void **)&g_stampbuf, 1 << 22); (void)hipMemset(g_stampbuf, 0, 1 << 22); }
+    if (epi == (getenv("SESRQ_STAMP_EPI") ? atoi(getenv("SESRQ_STAMP_EPI")) : 0) && lp.mfma_kind == (getenv("SESRQ_STAMP_KIND") ? atoi(getenv("SESRQ_STAMP_KIND")) : MFMA_H3)) a.dbg_pe = g_stampbuf;
+#endif
+    {   // persistent walk: ~3 workgroups per CU, each a vertical run of tiles
+        const int strips = (a.W + MTW - 1) / MTW, row_tiles = (a.H + MTH - 1) / MTH;
+        long long nchunks = (768 + (long long)strips * a.N / 2) / ((long long)strips * a.N);
+        nchunks = std::max(1LL, std::min<long long>(nchunks, row_tiles));
+        a.chunk_tiles = (int)((row_tiles + nchunks - 1) / nchunks);
+    }
+    if ((size_t)a.H * a.W * 16 >= ((size_t)1 << 28)) { set_error("mfma: frame too large for 32-bit buffer offsets (H*W must stay below 2^24 pixels)"); return 1; }
     const bool std_bits = a.acc_lo == -131072 && a.acc_hi == 131071 && a.add_lo == -524288 && a.add_hi == 524287;
     const int mode = !general ? MERGED : (std_bits ? GEN_STD : GEN_ANY);
     switch (lp.mfma_kind) {

@@ -1,0 +1,62 @@
+// Device helpers shared by the MFMA engines (per-layer: sesrq_mfma.hip, fused: sesrq_fused.hip).
+#pragma once
+#include "sesrq_common.h"
+
+namespace sesrq {
+
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef unsigned v4u __attribute__((ext_vector_type(4)));
+typedef unsigned v2u __attribute__((ext_vector_type(2)));
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+constexpr float MAGIC = 12582912.f;   // 1.5 * 2^23
+
+// accumulate modes
+enum { MERGED = 0, GEN_STD = 1, GEN_ANY = 2 };   // GEN_STD: 18/20-bit clamps as literals
+
+__device__ __forceinline__ v4i mfma(v4i a, v4i b, v4i c) { return __builtin_amdgcn_mfma_i32_16x16x64_i8(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ float med3(float v, float lo, float hi) { return __builtin_amdgcn_fmed3f(v, lo, hi); }
+__device__ __forceinline__ int clampi3(int v, int lo, int hi) { return min(max(v, lo), hi); }
+__device__ __forceinline__ v4i ld_frag(const int4 *p) { const int4 t = *p; v4i r = {t.x, t.y, t.z, t.w}; return r; }
+__device__ __forceinline__ unsigned fbits(float f) { return __builtin_bit_cast(unsigned, f); }
+
+// low bytes of four words -> one word
+__device__ __forceinline__ unsigned pack_lo_bytes(unsigned y0, unsigned y1, unsigned y2, unsigned y3) {
+    const unsigned w01 = __builtin_amdgcn_perm(y1, y0, 0x0c0c0400u);
+    const unsigned w23 = __builtin_amdgcn_perm(y3, y2, 0x0c0c0400u);
+    return __builtin_amdgcn_perm(w23, w01, 0x05040100u);
+}
+
+constexpr int MAGIC_I = 0x4B400000;   // bit pattern of MAGIC: int s (|s| < 2^22) + MAGIC_I == bits of (float)(MAGIC + s)
+
+// v[i] = fl(fl(s[i] * M) * 2^-n + zadd)   (un-rounded, two values per packed op)
+// BIASED: s[i] already carries + MAGIC_I, i.e. its bits ARE the float MAGIC + s (exact); then
+// fl(s*M) = fma(MAGIC + s, M, -MAGIC*M): the fma's product is exact, MAGIC*M = 3*M*2^22 is exactly
+// representable (3*M < 2^18), so the single rounding is that of the exact s*M -- no v_cvt_f32_i32.
+template <bool BIASED>
+__device__ __forceinline__ void requant4(const int s[4], float Mf, float sh, float zadd, v2f &v01, v2f &v23) {
+    const v2f M2 = {Mf, Mf}, sh2 = {sh, sh}, z2 = {zadd, zadd};
+    if constexpr (BIASED) {
+        const float c = -(MAGIC * Mf);
+        const v2f c2 = {c, c};
+        const v2f y01 = {__builtin_bit_cast(float, s[0]), __builtin_bit_cast(float, s[1])};
+        const v2f y23 = {__builtin_bit_cast(float, s[2]), __builtin_bit_cast(float, s[3])};
+        v01 = __builtin_elementwise_fma(__builtin_elementwise_fma(y01, M2, c2), sh2, z2);
+        v23 = __builtin_elementwise_fma(__builtin_elementwise_fma(y23, M2, c2), sh2, z2);
+    } else {
+        const v2f f01 = {(float)s[0], (float)s[1]}, f23 = {(float)s[2], (float)s[3]};
+        v01 = __builtin_elementwise_fma(f01 * M2, sh2, z2);
+        v23 = __builtin_elementwise_fma(f23 * M2, sh2, z2);
+    }
+}
+
+// clamp (un-rounded) then round-half-even to int8, 4 values -> packed word
+__device__ __forceinline__ unsigned round_pack(v2f v01, v2f v23, float lo, float hi) {
+    const v2f mg = {MAGIC, MAGIC};
+    v2f c01 = {med3(v01[0], lo, hi), med3(v01[1], lo, hi)}, c23 = {med3(v23[0], lo, hi), med3(v23[1], lo, hi)};
+    c01 = c01 + mg; c23 = c23 + mg;
+    return pack_lo_bytes(fbits(c01[0]), fbits(c01[1]), fbits(c23[0]), fbits(c23[1]));
+}
+
+
+}  // namespace sesrq

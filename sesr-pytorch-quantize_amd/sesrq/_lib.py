@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get("SESRQ_LIB") or os.path.normpath(os.path.join(_HERE, "
 MAX_LAYERS = 16
 MAX_CH = 16
 F32, I8 = 0, 1
-ENGINE_AUTO, ENGINE_DOT4, ENGINE_MFMA = 0, 1, 2
+ENGINE_AUTO, ENGINE_DOT4, ENGINE_MFMA, ENGINE_FUSED = 0, 1, 2, 3
 OPT_ENGINE, OPT_FORCE_GENERAL = 1, 2
 
 

@@ -68,8 +68,10 @@ class Engine:
         r = self.bundle.pixel_shuffle
         return (N, self.bundle.out_channels, H * r, W * r)
 
-    def workspace(self, N, H, W) -> torch.Tensor:
-        key = (N, H, W)
+    def workspace(self, N, H, W, slot: int = 0) -> torch.Tensor:
+        """Device workspace for (N,H,W); `slot` selects an independent copy so that several frames can be
+        in flight on different streams (the library itself keeps no per-call state)."""
+        key = (N, H, W, slot)
         ws = self._ws.get(key)
         if ws is None:
             nbytes = _lib.lib().sesrq_workspace_bytes(self._h, N, H, W)
@@ -90,8 +92,11 @@ class Engine:
             return _lib.I8
         raise ValueError("input must be float32 (frame) or int8 (already quantised q0)")
 
-    def forward(self, x: torch.Tensor, want_q: bool = True, want_f: bool = True, out_q=None, out_f=None):
-        """x: (N, Cin, H, W) float32 | int8 on self.device -> (q int8 | None, y float32 | None)."""
+    def forward(self, x: torch.Tensor, want_q: bool = True, want_f: bool = True, out_q=None, out_f=None, stream=None,
+                slot: int = 0):
+        """x: (N, Cin, H, W) float32 | int8 on self.device -> (q int8 | None, y float32 | None).
+        stream: torch.cuda.Stream to enqueue on (default: current); slot: workspace copy to use -- give
+        concurrent in-flight frames different slots."""
         dt = self._check_in(x)
         x = x.contiguous()
         N, _, H, W = x.shape
@@ -100,8 +105,8 @@ class Engine:
             out_q = torch.empty(shp, dtype=torch.int8, device=self.device)
         if want_f and out_f is None:
             out_f = torch.empty(shp, dtype=torch.float32, device=self.device)
-        ws = self.workspace(N, H, W)
-        st = torch.cuda.current_stream(self.device).cuda_stream
+        ws = self.workspace(N, H, W, slot)
+        st = (stream if stream is not None else torch.cuda.current_stream(self.device)).cuda_stream
         rc = _lib.lib().sesrq_forward(self._h, x.data_ptr(), dt, out_q.data_ptr() if out_q is not None else None,
                                       out_f.data_ptr() if out_f is not None else None, N, H, W, ws.data_ptr(),
                                       ws.numel(), st)

@@ -18,7 +18,18 @@ from sesrq import _lib
 pytestmark = pytest.mark.gpu
 
 STAGE_FILES = [f for f in golden_files() if not f.endswith((".params.npz", "tables.npz"))]
-ENGINES = [("dot4", _lib.ENGINE_DOT4), ("mfma", _lib.ENGINE_MFMA)]
+ENGINES = [("dot4", _lib.ENGINE_DOT4), ("mfma", _lib.ENGINE_MFMA), ("fused", _lib.ENGINE_FUSED)]
+
+
+def make_engine(net, eng, **kw):
+    """Engine on the requested kernel family; the fused engine only takes the reference topology
+    with zero[1] == -128 (always true after calibration: ReLU output min is 0) -> skip otherwise."""
+    try:
+        return sesrq.Engine(bundle_from_oracle(net), _dev(), engine=eng[1], **kw)
+    except ValueError as e:
+        if eng[0] == "fused" and "not eligible" in str(e):
+            pytest.skip("net not eligible for the fused engine")
+        raise
 
 
 def _sha(a):
@@ -46,12 +57,12 @@ def test_golden_stage_by_stage(path, eng):
     """Every tensor the reference dumped (input.K, pe_outputK_P, pe_add_outputK, final) on the
     reference's own inputs, including the adversarial zero-point / saturating-weight runs."""
     fx, meta, net, x = fixture_case(path)
-    e = sesrq.Engine(bundle_from_oracle(net), _dev(), engine=eng[1])
+    e = make_engine(net, eng)
     xt = torch.from_numpy(x).to(_dev())
     use_pe = eng[0] == "dot4"        # the PE dump taps are a dot4-engine feature; with them a layer runs on dot4
     res = e.forward_debug(xt, pe=use_pe)
-    if eng[0] == "mfma":
-        assert all(s.startswith("mfma") for s in e.layer_engines()), e.layer_engines()
+    if eng[0] != "dot4":
+        assert all(s.startswith(eng[0]) for s in e.layer_engines()), e.layer_engines()
     r = net.pixel_shuffle
     got = {k: v.cpu().numpy() for k, v in res.items()}
     # un-shuffle q_out to compare with input5
@@ -69,10 +80,11 @@ def test_golden_stage_by_stage(path, eng):
     for name in fx.files:
         if name in got and name not in ("x",):
             _cmp(name, got[name], fx[name])
-    # production call (no taps) must give the same result as the debug call
+    # production call (no taps; this is where the fused engine runs) must give the same result
     q, y = e.forward(xt)
     _cmp("q_out(production)", q, got["q_out"])
     _cmp("y(production)", y, got["y"])
+    _cmp("q_out(production) vs golden input5", np.ascontiguousarray(q.cpu().numpy().reshape(N, C, Ho // r, r, Wo // r, r).transpose(0, 1, 3, 5, 2, 4).reshape(q5.shape)), fx["input5"])
 
 
 SIZES = [(1, 1, 1), (1, 3, 5), (1, 8, 32), (1, 9, 33), (2, 17, 70), (1, 40, 129), (3, 31, 64)]
@@ -86,7 +98,9 @@ def test_synthetic_nets_vs_oracle(kind, hard, eng):
     zero points -> general kernels with the 18/20-bit clamps firing), ragged sizes, batches."""
     for seed in range(2):
         net = O.synth_net(kind, seed, hard=hard)
-        e = sesrq.Engine(bundle_from_oracle(net), _dev(), engine=eng[1])
+        if eng[0] == "fused":
+            net.zero[1] = -128          # the fused engine's precondition (see make_engine)
+        e = make_engine(net, eng)
         cin = net.layers[0].wq.shape[1]
         for (N, H, W) in SIZES:
             x = rand_frame((N, cin, H, W), 1000 * seed + H * W)
@@ -100,10 +114,9 @@ def test_synthetic_nets_vs_oracle(kind, hard, eng):
 def test_general_and_merged_kernels_agree(eng):
     """force_general runs the per-PE kernels on a saturation-free bundle: same bits."""
     net = O.synth_net("sesr_x2", 5)
-    b = bundle_from_oracle(net)
     x = torch.from_numpy(rand_frame((2, 3, 37, 91), 9)).to(_dev())
-    e0 = sesrq.Engine(b, _dev(), engine=eng[1])
-    e1 = sesrq.Engine(b, _dev(), engine=eng[1], force_general=True)
+    e0 = make_engine(net, eng)
+    e1 = make_engine(net, eng, force_general=True)
     assert any("merged" in s for s in e0.layer_engines())
     q0, y0 = e0.forward(x)
     q1, y1 = e1.forward(x)
@@ -143,6 +156,7 @@ def test_full_size_properties_1080p():
     (c) determinism: two runs give identical bytes."""
     net = O.synth_net("sesr_x2", 0)
     e = sesrq.Engine(bundle_from_oracle(net), _dev())
+    assert e.layer_engines()[0].startswith("fused"), "default engine for the reference topology is the fused one"
     x = torch.from_numpy(rand_frame((1, 3, 1080, 1920), 2)).to(_dev())
     q, y = e.forward(x)
     q2, _ = e.forward(x)
