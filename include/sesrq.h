@@ -33,7 +33,7 @@ enum { SESRQ_F32 = 0, SESRQ_I8 = 1 };
 
 /* kernel families (sesrq_set_option(net, SESRQ_OPT_ENGINE, ...)) */
 enum { SESRQ_ENGINE_AUTO = 0, SESRQ_ENGINE_DOT4 = 1, SESRQ_ENGINE_MFMA = 2, SESRQ_ENGINE_FUSED = 3 };
-enum { SESRQ_OPT_ENGINE = 1, SESRQ_OPT_FORCE_GENERAL = 2 };
+enum { SESRQ_OPT_ENGINE = 1, SESRQ_OPT_FORCE_GENERAL = 2, SESRQ_OPT_EXACT_DIV = 3 };
 
 /* One collapsed convolution with its integer epilogue.
  *   w         : conv.weight.K.pt   (myQL/quan_func.py:71,78)  [oc][ic][k][k] int8
@@ -79,6 +79,9 @@ typedef struct sesrq_net sesrq_net;
 int sesrq_create(const sesrq_net_desc *desc, sesrq_net **out);
 void sesrq_destroy(sesrq_net *net);
 int sesrq_set_option(sesrq_net *net, int option, int value);
+/* 1 if sesrq_create proved (exhaustively, on the device) that the 3-instruction reciprocal form of
+ * the input quantiser's x / scale_in is bit-identical for this net; 0 = IEEE division is used. */
+int sesrq_fast_division_proven(const sesrq_net *net);
 
 /* Bytes of device workspace sesrq_forward needs for N frames of H x W (caller-owned). */
 size_t sesrq_workspace_bytes(const sesrq_net *net, int N, int H, int W);

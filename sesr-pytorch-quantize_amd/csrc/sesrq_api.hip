@@ -254,6 +254,8 @@ int sesrq_create(const sesrq_net_desc *d, sesrq_net **out) {
         lp.engine_mfma = lp.mfma_kind == MFMA_NONE ? lp.engine_dot4 : std::string(kn[lp.mfma_kind]) + (lp.general ? "-general" : "-merged");
         lp.engine = lp.engine_mfma;
     }
+    net->fd = prove_fastdiv(d->scale_in, d->zero[0]);
+    net->layers[0].base.fd = net->fd;
     // fused engine: reference topology 5x5 / 3x3 x3 / 5x5, standard 18/20-bit PE model, z1 == -128
     net->fused_ok = (L == 5) && net->layers[0].mfma_kind == MFMA_F5 && net->layers[1].mfma_kind == MFMA_H3 &&
                     net->layers[2].mfma_kind == MFMA_H3 && net->layers[3].mfma_kind == MFMA_H3 &&
@@ -284,6 +286,7 @@ int sesrq_set_option(sesrq_net *net, int option, int value) {
             for (auto &lp : net->layers) lp.engine = (value == SESRQ_ENGINE_DOT4) ? lp.engine_dot4 : lp.engine_mfma;
             return 0;
         case SESRQ_OPT_FORCE_GENERAL: net->force_general = value ? 1 : 0; return 0;
+        case SESRQ_OPT_EXACT_DIV: net->force_exact_div = value ? 1 : 0; return 0;
     }
     set_error("sesrq_set_option: unknown option");
     return 1;
@@ -292,6 +295,8 @@ int sesrq_set_option(sesrq_net *net, int option, int value) {
 static bool use_fused(const sesrq_net *net, int in_dtype, const sesrq_taps *taps) {
     return net->fused_ok && (net->engine == SESRQ_ENGINE_AUTO || net->engine == SESRQ_ENGINE_FUSED) && in_dtype == SESRQ_F32 && !taps;
 }
+
+int sesrq_fast_division_proven(const sesrq_net *net) { return net ? net->fd.ok : 0; }
 
 const char *sesrq_layer_engine(const sesrq_net *net, int k) {
     if (!net || k < 0 || k >= net->L) return "";
@@ -334,6 +339,7 @@ static int forward_impl(const sesrq_net *net, const void *in, int in_dtype, void
         f.chunk = (H + nchunks - 1) / nchunks;
         const ConvArgs &a0 = net->layers[0].base, &a4 = net->layers[4].base;
         f.pad_in0 = a0.pad_word;
+        f.fd = net->force_exact_div ? FastDiv{0, 0.f, 0.f, 0.f} : net->fd;
         f.s_in = a0.s_in; f.z_in = a0.z_in; f.s_out = a4.s_out; f.z_out = a4.z_out;
         f.Mres = a0.Mres; f.shres = a0.shres; f.z_merge = a0.z_merge;
         bool gen[5];
@@ -366,6 +372,7 @@ static int forward_impl(const sesrq_net *net, const void *in, int in_dtype, void
         eff.general = lp.general || net->force_general || dbg;
         a.wpk = eff.general ? lp.d_wpk_general : lp.d_wpk_merged;
         a.N = N; a.H = H; a.W = W;
+        if (net->force_exact_div) a.fd.ok = 0;
         a.in = cur;
         int src = (k == 0) ? (in_dtype == SESRQ_F32 ? SRC_F32 : SRC_I8) : SRC_NHWC16;
         int epi = (k == L - 1) ? EPI_LAST : (k == L - 2 ? EPI_PRERES : EPI_MID);

@@ -13,6 +13,14 @@ enum Epi { EPI_MID = 0, EPI_PRERES = 1, EPI_LAST = 2 };
 enum Src { SRC_NHWC16 = 0, SRC_F32 = 1, SRC_I8 = 2 };
 enum MfmaKind { MFMA_NONE = 0, MFMA_H3 = 1, MFMA_H5 = 2, MFMA_F5 = 3 };
 
+// Verified fast division of the input quantiser (sesrq_verify.hip): q0(x) with x pre-clamped to
+// [xlo, xhi] and x/s formed as fma(fma(-s, x*r, x), r, x*r); ok == 1 only after an exhaustive proof.
+struct FastDiv {
+    int ok;
+    float r, xlo, xhi;
+};
+FastDiv prove_fastdiv(float s, int zero);
+
 // Per-launch arguments of one conv layer.  Lives in the kernarg segment (SGPR loads).
 struct ConvArgs {
     const void *in;          // SRC_NHWC16: uint4 per pixel ; SRC_F32/SRC_I8: NCHW planes
@@ -36,6 +44,7 @@ struct ConvArgs {
     float Mres, shres;       // EPI_PRERES
     float z_merge;           // EPI_PRERES: zero of the last conv's input domain
     float s_in, z_in;        // SRC_F32: f32(scale_0), (float)zero_0
+    FastDiv fd;              // SRC_F32: proven fast form of x / s_in (fd.ok == 0 -> IEEE division)
     float s_out, z_out;      // EPI_LAST: f32(scale_L), (float) zero_L
     int relu;
     int ps;                  // EPI_LAST pixel shuffle factor
@@ -55,6 +64,7 @@ struct FusedArgs {
     int N, H, W, ic, oc, ps, chunk;
     int pad_in0;
     float s_in, z_in, s_out, z_out, Mres, shres, z_merge;
+    FastDiv fd;
     FusedLayer l[5];
 };
 
@@ -94,7 +104,9 @@ struct sesrq_net {
     int acc_bits = 18, add_bits = 20;
     int engine = SESRQ_ENGINE_AUTO;
     int force_general = 0;
+    int force_exact_div = 0;
     int device = 0;
     bool rc_separate = false;   // zero[1] != -128 -> layer 0 writes its own rc tensor
+    sesrq::FastDiv fd = {0, 0.f, 0.f, 0.f};
     bool fused_ok = false;      // topology/parameters eligible for the fused engine
 };

@@ -116,7 +116,7 @@ __global__ __launch_bounds__(256, 2) void fused5_kernel(const FusedArgs a) {
         for (int j = 0; j < 2; ++j) {
             if (tid + 256 * j < nel) {
                 const bool ok = (r >= 0) & (r < H) & (e_x[j] >= 0) & (e_x[j] < W);
-                int q = (int)med3(rintf(__fadd_rn(__fdiv_rn(v[j], a.s_in), a.z_in)), -128.f, 127.f);
+                int q = (int)quantize_in(v[j], a.s_in, a.z_in, a.fd);
                 if (!ok) q = padb0;
 #pragma unroll
                 for (int s = 0; s < 4; ++s) {

@@ -29,6 +29,10 @@
 //     monotone rounding commute with the clamp; fl(max(t,0)+z) == max(fl(t+z), z));
 //   * rint + float->int8 is one add of 1.5*2^23 (round-to-nearest-even into the low mantissa
 //     bits) followed by a byte pick; mul / fma / magic-add run as packed v_pk_*_f32.
+#include <algorithm>
+#include <map>
+#include <mutex>
+
 #include "sesrq_mfma_common.h"
 
 namespace sesrq {
@@ -524,7 +528,7 @@ struct StageFrame {
             for (int c = 0; c < 4; ++c) {
                 int q;
                 if constexpr (SRC == SRC_F32)
-                    q = (int)med3(rintf(__fadd_rn(__fdiv_rn(__builtin_bit_cast(float, raw[it][c]), a.s_in), a.z_in)), -128.f, 127.f);
+                    q = (int)quantize_in(__builtin_bit_cast(float, raw[it][c]), a.s_in, a.z_in, a.fd);
                 else
                     q = (int)raw[it][c];
                 if (c < a.ic) word |= (q & 0xff) << (8 * c);
@@ -622,10 +626,37 @@ extern "C" int sesrq_debug_fetch_stamps(void *host, size_t bytes) {
     return g_stampbuf ? (int)hipMemcpy(host, g_stampbuf, bytes, hipMemcpyDeviceToHost) : -1;
 }
 #endif
+// Persistent walk geometry: one round of workgroups that exactly fits the chip.  The number of
+// co-resident workgroups per CU comes from the occupancy API for THIS kernel (registers / LDS differ a
+// lot between the merged and general variants); a strip's row tiles are then cut into the largest
+// number of equal vertical runs that still fits.
 template <typename K>
-static void launch(K kern, const ConvArgs &a, hipStream_t st) {
-    const int row_tiles = (a.H + MTH - 1) / MTH;
-    dim3 grid((a.W + MTW - 1) / MTW, (row_tiles + a.chunk_tiles - 1) / a.chunk_tiles, a.N);
+static void launch(K kern, ConvArgs a, hipStream_t st) {
+    static std::mutex mu;
+    static std::map<const void *, int> occ;          // per kernel (all instantiations share this function type)
+    static int num_cu = 0;
+    int blocks_per_cu;
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        if (!num_cu) {
+            int dev = 0;
+            hipDeviceProp_t prop;
+            if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) num_cu = prop.multiProcessorCount;
+            if (num_cu < 1) num_cu = 256;
+        }
+        auto it = occ.find((const void *)kern);
+        if (it == occ.end()) {
+            int b = 0;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, kern, 256, 0) != hipSuccess || b < 1) b = 2;
+            it = occ.emplace((const void *)kern, b).first;
+        }
+        blocks_per_cu = it->second;
+    }
+    const int strips = (a.W + MTW - 1) / MTW, row_tiles = (a.H + MTH - 1) / MTH;
+    long long k = ((long long)blocks_per_cu * num_cu) / ((long long)strips * a.N);
+    k = std::max(1LL, std::min<long long>(k, row_tiles));
+    a.chunk_tiles = (int)((row_tiles + k - 1) / k);
+    dim3 grid(strips, (row_tiles + a.chunk_tiles - 1) / a.chunk_tiles, a.N);
     hipLaunchKernelGGL(kern, grid, dim3(256), 0, st, a);
 }
 
@@ -642,12 +673,6 @@ int launch_mfma(const LayerPlan &lp, const ConvArgs &a_in, int src, int epi, boo
     if (!g_stampbuf) { (void)hipMalloc((void **)&g_stampbuf, 1 << 22); (void)hipMemset(g_stampbuf, 0, 1 << 22); }
     if (epi == (getenv("SESRQ_STAMP_EPI") ? atoi(getenv("SESRQ_STAMP_EPI")) : 0) && lp.mfma_kind == (getenv("SESRQ_STAMP_KIND") ? atoi(getenv("SESRQ_STAMP_KIND")) : MFMA_H3)) a.dbg_pe = g_stampbuf;
 #endif
-    {   // persistent walk: ~3 workgroups per CU, each a vertical run of tiles
-        const int strips = (a.W + MTW - 1) / MTW, row_tiles = (a.H + MTH - 1) / MTH;
-        long long nchunks = (768 + (long long)strips * a.N / 2) / ((long long)strips * a.N);
-        nchunks = std::max(1LL, std::min<long long>(nchunks, row_tiles));
-        a.chunk_tiles = (int)((row_tiles + nchunks - 1) / nchunks);
-    }
     if ((size_t)a.H * a.W * 16 >= ((size_t)1 << 28)) { set_error("mfma: frame too large for 32-bit buffer offsets (H*W must stay below 2^24 pixels)"); return 1; }
     const bool std_bits = a.acc_lo == -131072 && a.acc_hi == 131071 && a.add_lo == -524288 && a.add_hi == 524287;
     const int mode = !general ? MERGED : (std_bits ? GEN_STD : GEN_ANY);

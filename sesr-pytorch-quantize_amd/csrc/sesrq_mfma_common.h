@@ -20,6 +20,19 @@ __device__ __forceinline__ int clampi3(int v, int lo, int hi) { return min(max(v
 __device__ __forceinline__ v4i ld_frag(const int4 *p) { const int4 t = *p; v4i r = {t.x, t.y, t.z, t.w}; return r; }
 __device__ __forceinline__ unsigned fbits(float f) { return __builtin_bit_cast(unsigned, f); }
 
+// input quantiser q0 = clamp8(rint(fl(fl(x/s) + z)))  (myQL/quan_func.py:225), as a float in [-128,127]
+__device__ __forceinline__ float quantize_in(float x, float s, float z, const FastDiv &fd) {
+    float t;
+    if (fd.ok) {                       // proven bit-identical for this (s, z): sesrq_verify.hip
+        const float xc = med3(x, fd.xlo, fd.xhi);
+        const float q = __fmul_rn(xc, fd.r);
+        t = __builtin_fmaf(__builtin_fmaf(-s, q, xc), fd.r, q);
+    } else {
+        t = __fdiv_rn(x, s);
+    }
+    return med3(rintf(__fadd_rn(t, z)), -128.f, 127.f);
+}
+
 // low bytes of four words -> one word
 __device__ __forceinline__ unsigned pack_lo_bytes(unsigned y0, unsigned y1, unsigned y2, unsigned y3) {
     const unsigned w01 = __builtin_amdgcn_perm(y1, y0, 0x0c0c0400u);

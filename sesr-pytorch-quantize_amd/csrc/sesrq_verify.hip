@@ -1,0 +1,86 @@
+// Verified fast division for the input quantiser.
+//
+// The reference quantises the frame with a TRUE fp32 division (myQL/quan_func.py:225):
+//     q0(x) = clamp8(rint(fl(fl(x / s) + z)))
+// An IEEE-correct division costs ~12 VALU instructions per element on gfx950 and is half of the
+// first layer's instruction stream.  Because s is one scalar per net, the quotient can instead be
+// formed with the correctly rounded reciprocal r = RN(1/s) and one Newton/Markstein correction,
+//     q = x*r ;  rem = fma(-s, q, x) ;  q' = fma(rem, r, q)            (3 instructions)
+// which equals RN(x/s) for all but (possibly) pathological operands.  "Possibly" is not good
+// enough for a bit-exact path, so sesrq_create PROVES it for the net's own (s, z): a kernel
+// enumerates EVERY fp32 value x in [xlo, xhi] -- a range whose ends already saturate to -128 / 127,
+// inputs are clamped to it first -- and compares the final int8 of the fast form with the true
+// division.  ~2e9 values, about a millisecond of GPU time, cached per (s, z).  Any mismatch (or a
+// range that does not saturate) disables the fast path for that net.
+#include <cmath>
+#include <map>
+#include <mutex>
+#include <utility>
+
+#include "sesrq_common.h"
+
+namespace sesrq {
+
+__device__ __forceinline__ float q8_exact(float x, float s, float z) {
+    return __builtin_amdgcn_fmed3f(rintf(__fadd_rn(__fdiv_rn(x, s), z)), -128.f, 127.f);
+}
+__device__ __forceinline__ float q8_fast(float x, float s, float r, float z) {
+    const float q = __fmul_rn(x, r);
+    const float rem = __builtin_fmaf(-s, q, x);
+    const float q1 = __builtin_fmaf(rem, r, q);
+    return __builtin_amdgcn_fmed3f(rintf(__fadd_rn(q1, z)), -128.f, 127.f);
+}
+
+// bit patterns [b0, b1] (same sign, increasing magnitude)
+__global__ void verify_fastdiv_kernel(unsigned b0, unsigned b1, float s, float r, float z, unsigned long long *bad) {
+    const unsigned long long n = (unsigned long long)b1 - b0 + 1;
+    unsigned long long local = 0;
+    for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (unsigned long long)gridDim.x * blockDim.x) {
+        const float x = __builtin_bit_cast(float, (unsigned)(b0 + i));
+        local += (q8_exact(x, s, z) != q8_fast(x, s, r, z)) ? 1 : 0;
+    }
+    if (local) atomicAdd(bad, local);
+}
+
+static std::mutex g_mu;
+static std::map<std::pair<unsigned, int>, FastDiv> g_cache;
+
+FastDiv prove_fastdiv(float s, int zero) {
+    FastDiv fd;
+    fd.ok = 0; fd.r = 0.f; fd.xlo = 0.f; fd.xhi = 0.f;
+    if (!(s > 0.f) || !std::isfinite(s)) return fd;
+    const std::pair<unsigned, int> key(__builtin_bit_cast(unsigned, s), zero);
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        auto it = g_cache.find(key);
+        if (it != g_cache.end()) return it->second;
+    }
+    const float z = (float)zero;
+    fd.r = (float)(1.0L / (long double)s);
+    fd.xlo = (float)((-136.0 - (double)zero) * (double)s);
+    fd.xhi = (float)((135.0 - (double)zero) * (double)s);
+    bool ok = std::isfinite(fd.r) && std::isfinite(fd.xlo) && std::isfinite(fd.xhi) && fd.r > 0.f;
+    unsigned long long *d_bad = nullptr;
+    if (ok && hipMalloc((void **)&d_bad, sizeof(*d_bad)) == hipSuccess && hipMemset(d_bad, 0, sizeof(*d_bad)) == hipSuccess) {
+        auto run = [&](float a, float b) {   // all floats between a and b, same sign, |a| <= |b|
+            const unsigned ua = __builtin_bit_cast(unsigned, a), ub = __builtin_bit_cast(unsigned, b);
+            hipLaunchKernelGGL(verify_fastdiv_kernel, dim3(4096), dim3(256), 0, 0, ua, ub, s, fd.r, z, d_bad);
+        };
+        if (fd.xlo < 0.f) { run(-0.0f, fd.xlo); if (fd.xhi >= 0.f) run(0.0f, fd.xhi); else run(fd.xhi, fd.xlo); }   // (both negative: |xhi| <= |xlo|)
+        else run(fd.xlo, fd.xhi);
+        unsigned long long bad = 1;
+        ok = hipMemcpy(&bad, d_bad, sizeof(bad), hipMemcpyDeviceToHost) == hipSuccess && bad == 0;
+        // the clamp range must saturate on both sides (host check with the exact formula)
+        const float lo_q = fminf(fmaxf(rintf(fd.xlo / s + z), -128.f), 127.f), hi_q = fminf(fmaxf(rintf(fd.xhi / s + z), -128.f), 127.f);
+        ok = ok && lo_q == -128.f && hi_q == 127.f;
+    } else {
+        ok = false;
+    }
+    if (d_bad) (void)hipFree(d_bad);
+    fd.ok = ok ? 1 : 0;
+    std::lock_guard<std::mutex> lk(g_mu);
+    g_cache[key] = fd;
+    return fd;
+}
+
+}  // namespace sesrq

@@ -16,7 +16,7 @@ MAX_LAYERS = 16
 MAX_CH = 16
 F32, I8 = 0, 1
 ENGINE_AUTO, ENGINE_DOT4, ENGINE_MFMA, ENGINE_FUSED = 0, 1, 2, 3
-OPT_ENGINE, OPT_FORCE_GENERAL = 1, 2
+OPT_ENGINE, OPT_FORCE_GENERAL, OPT_EXACT_DIV = 1, 2, 3
 
 
 class LayerDesc(C.Structure):
@@ -42,6 +42,7 @@ SYMBOLS = {
     "sesrq_create": (C.c_int, [C.POINTER(NetDesc), C.POINTER(C.c_void_p)]),
     "sesrq_destroy": (None, [C.c_void_p]),
     "sesrq_set_option": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
+    "sesrq_fast_division_proven": (C.c_int, [C.c_void_p]),
     "sesrq_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_int, C.c_int, C.c_int]),
     "sesrq_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                 C.c_void_p, C.c_size_t, C.c_void_p]),

@@ -17,7 +17,7 @@ class Engine:
     the workspace for a given (N, H, W) exists."""
 
     def __init__(self, bundle: Bundle, device: Optional[torch.device] = None, engine: int = _lib.ENGINE_AUTO,
-                 force_general: bool = False):
+                 force_general: bool = False, exact_division: bool = False):
         if not torch.cuda.is_available():
             raise RuntimeError("sesrq.Engine needs a HIP device (torch.cuda.is_available() is False); "
                                "there is no CPU fallback in this package")
@@ -47,6 +47,8 @@ class Engine:
             _lib.check(_lib.lib().sesrq_set_option(self._h, _lib.OPT_ENGINE, engine), ValueError)
         if force_general:
             _lib.check(_lib.lib().sesrq_set_option(self._h, _lib.OPT_FORCE_GENERAL, 1), ValueError)
+        if exact_division:
+            _lib.check(_lib.lib().sesrq_set_option(self._h, _lib.OPT_EXACT_DIV, 1), ValueError)
         self._ws: Dict[tuple, torch.Tensor] = {}
 
     def close(self):
@@ -61,6 +63,9 @@ class Engine:
             pass
 
     # ------------------------------------------------------------------
+    def fast_division_proven(self) -> bool:
+        return bool(_lib.lib().sesrq_fast_division_proven(self._h))
+
     def layer_engines(self):
         return [(_lib.lib().sesrq_layer_engine(self._h, k) or b"").decode() for k in range(self.bundle.L)]
 

@@ -190,3 +190,30 @@ def test_error_conventions():
     bad.pe_num = 8
     with pytest.raises(ValueError, match="pe_num"):
         sesrq.Engine(bad, _dev())
+
+
+def test_fast_division_is_proven_and_equals_exact_division():
+    """The 3-instruction reciprocal form of the input quantiser is used only after sesrq_create proved it
+    exhaustively for the net's (scale, zero); with the proof on or forced off the bits are the same, on
+    adversarial inputs too (ties of x/s+z at .5, denormals, huge / negative values)."""
+    net = O.synth_net("sesr_x2", 1)
+    b = bundle_from_oracle(net)
+    e_fast = sesrq.Engine(b, _dev(), engine=_lib.ENGINE_MFMA)
+    e_exact = sesrq.Engine(b, _dev(), engine=_lib.ENGINE_MFMA, exact_division=True)
+    assert e_fast.fast_division_proven()
+    rng = np.random.default_rng(0)
+    s0, z0 = np.float32(net.scale[0]), net.zero[0]
+    x = rng.random((1, 3, 64, 96), dtype=np.float32)
+    ties = ((np.arange(-140, 140, dtype=np.float64) + 0.5 - z0) * float(s0)).astype(np.float32)   # x/s+z near k+.5
+    x[0, 0, 0, :len(ties[:96])] = ties[:96]
+    x[0, 1, 1, :96] = np.nextafter(ties[96:192], np.float32(1e9))
+    x[0, 2, 2, :88] = np.nextafter(ties[192:280], np.float32(-1e9))
+    x[0, 0, 3, :8] = np.array([0.0, -0.0, 1e-42, -1e-42, 3.0e38, -3.0e38, 1e-30, 123456.0], np.float32)
+    xt = torch.from_numpy(x).to(_dev())
+    qa, _ = e_fast.forward(xt)
+    qb, _ = e_exact.forward(xt)
+    assert torch.equal(qa, qb)
+    _cmp("vs oracle", qa, O.forward(net, x)["q_out"])
+    for tag in ("sesr_x4", "nrdm_3", "sesr_x2_rand"):
+        fx, meta, gnet, gx = fixture_case(os.path.join(os.path.dirname(STAGE_FILES[0]), f"{tag}.crop.npz"))
+        assert sesrq.Engine(bundle_from_oracle(gnet), _dev()).fast_division_proven(), tag
