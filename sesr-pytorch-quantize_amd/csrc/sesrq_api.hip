@@ -51,11 +51,13 @@ static void pack_weights(const sesrq_layer_desc &d, int ocp, bool first, std::ve
 // for q in [-128,127] (pad value included) the extreme PE sums are 127*S+ + 128*S- and
 // -(128*S+ + 127*S-).  (myQL/quan_func.py:358-370,437 are then identities.)
 static bool saturation_free(const sesrq_layer_desc &d, int zc, int acc_bits, int add_bits, long long &worst_pe,
-                            long long &worst_sum) {
+                            long long &worst_sum, int &risky_mask) {
+    risky_mask = 0;
     const int taps = d.k * d.k;
     const long long acc_hi = (1LL << (acc_bits - 1)) - 1, add_hi = (1LL << (add_bits - 1)) - 1;
     worst_pe = worst_sum = 0;
     bool ok = (zc >= -128 && zc <= 127);
+    if (!ok) risky_mask = 15;
     for (int o = 0; o < d.oc; ++o) {
         long long tot_hi = 0, tot_lo = 0;
         for (int p = 0; p < 4; ++p) {
@@ -67,7 +69,7 @@ static bool saturation_free(const sesrq_layer_desc &d, int zc, int acc_bits, int
                 }
             const long long hi = 127 * sp + 128 * sn, lo = 128 * sp + 127 * sn;
             worst_pe = std::max(worst_pe, std::max(hi, lo));
-            if (hi > acc_hi || lo > acc_hi + 1) ok = false;
+            if (hi > acc_hi || lo > acc_hi + 1) { ok = false; risky_mask |= 1 << p; }
             tot_hi += hi; tot_lo += lo;
         }
         worst_sum = std::max(worst_sum, std::max(tot_hi, tot_lo));
@@ -205,7 +207,7 @@ int sesrq_create(const sesrq_net_desc *d, sesrq_net **out) {
         lp.k = l.k; lp.ic = l.ic; lp.oc = l.oc;
         lp.ocp = (k == L - 1) ? ((l.oc + 3) & ~3) : 16;
         const int zc = std::max(d->zero[k], -128);
-        lp.general = !saturation_free(l, zc, d->pe_acc_bits, d->pe_add_bits, lp.worst_pe, lp.worst_sum);
+        lp.general = !saturation_free(l, zc, d->pe_acc_bits, d->pe_add_bits, lp.worst_pe, lp.worst_sum, lp.risky_mask);
         std::vector<int> gen, mer;
         pack_weights(l, lp.ocp, k == 0, gen, mer);
         const size_t bytes = gen.size() * sizeof(int);
@@ -251,7 +253,8 @@ int sesrq_create(const sesrq_net_desc *d, sesrq_net **out) {
         for (int o = 0; o < l.oc; ++o) a.add_const[o] = l.add_const[o];
         lp.engine_dot4 = lp.general ? "dot4-general" : "dot4-merged";
         static const char *kn[] = {"", "mfma-h3", "mfma-h5", "mfma-f5"};
-        lp.engine_mfma = lp.mfma_kind == MFMA_NONE ? lp.engine_dot4 : std::string(kn[lp.mfma_kind]) + (lp.general ? "-general" : "-merged");
+        const bool hyb = lp.general && __builtin_popcount(lp.risky_mask) == 1 && d->pe_acc_bits == 18 && d->pe_add_bits == 20;
+        lp.engine_mfma = lp.mfma_kind == MFMA_NONE ? lp.engine_dot4 : std::string(kn[lp.mfma_kind]) + (hyb ? "-hybrid" : (lp.general ? "-general" : "-merged"));
         lp.engine = lp.engine_mfma;
     }
     net->fd = prove_fastdiv(d->scale_in, d->zero[0]);
@@ -394,7 +397,10 @@ static int forward_impl(const sesrq_net *net, const void *in, int in_dtype, void
         const bool use_mfma = net->engine != SESRQ_ENGINE_DOT4 && lp.mfma_kind != MFMA_NONE && !dbg;
         if (use_mfma) {
             a.afrag = eff.general ? lp.d_afrag_general : lp.d_afrag_merged;
-            if (launch_mfma(lp, a, src, epi, eff.general, st)) return 1;
+            // exactly one PE can saturate (and nothing forces the full per-PE path): merged chain + that PE's chain
+            const bool one_pe = lp.general && !net->force_general && !dbg && __builtin_popcount(lp.risky_mask) == 1;
+            if (one_pe) { a.afrag = lp.d_afrag_merged; a.afrag2 = lp.d_afrag_general; a.risky_pe = __builtin_ctz(lp.risky_mask); }
+            if (launch_mfma(lp, a, src, epi, eff.general, st, one_pe)) return 1;
         } else if (launch_dot4(eff, a, src, epi, st)) return 1;
         if (ev && hipEventRecord(ev[2 * k + 1], st) != hipSuccess) { set_error("hipEventRecord failed"); return 1; }
         cur = dst;

@@ -31,6 +31,8 @@ struct ConvArgs {
     float *out_f;            // EPI_LAST: same shape fp32 or NULL
     const int *wpk;          // dot4: packed weights [tap][OCP][4] dwords (see pack_weights)
     const int4 *afrag;       // mfma: [4] add-constant words (row order) + A fragments [F][64] (pack_mfma_frags)
+    const int4 *afrag2;      // mfma hybrid mode: the per-PE (general) fragment image; risky_pe selects the chain
+    int risky_pe;
     int *dbg_pe;             // (N,4,OC,H,W) int32 or NULL
     int *dbg_add;            // (N,OC,H,W) int32 or NULL
     signed char *dbg_q0;     // (N,IC,H,W) int8: quantised input of layer 0 or NULL
@@ -81,6 +83,7 @@ struct LayerPlan {
     ConvArgs base;           // constant fields prefilled
     // static saturation analysis (per layer)
     long long worst_pe = 0, worst_sum = 0;
+    int risky_mask = 0;      // PEs (bit p) whose 18-bit clamp can fire for some output channel
 };
 
 void set_error(const std::string &msg);
@@ -88,7 +91,7 @@ void set_error(const std::string &msg);
 // dot4 engine
 int launch_dot4(const LayerPlan &lp, const ConvArgs &a, int src, int epi, hipStream_t st);
 // mfma engine
-int launch_mfma(const LayerPlan &lp, const ConvArgs &a, int src, int epi, bool general, hipStream_t st);
+int launch_mfma(const LayerPlan &lp, const ConvArgs &a, int src, int epi, bool general, hipStream_t st, bool one_risky_pe = false);
 int launch_fused5(const FusedArgs &a, bool gen0, bool genh, bool gen4, hipStream_t st);
 int launch_unpack_nhwc16(const void *nhwc, signed char *nchw, int N, int C, int H, int W, hipStream_t st);
 

@@ -131,6 +131,10 @@ __device__ __forceinline__ void finish_sums(int s[4], const v4i *acc, const int4
     for (int i = 0; i < 4; ++i) {
         if constexpr (MODE == MERGED) {
             s[i] = acc[0][i];       // add constant already in the accumulator (C-in)
+        } else if constexpr (MODE == HYB) {
+            // acc[0] = sum over ALL PEs (none of the other three can saturate: load-time proof), acc[1] = the risky PE
+            const int t = acc[0][i] + (clampi3(acc[1][i], -131072, 131071) - acc[1][i]);
+            s[i] = clampi3(t, -524288, 524287) + acv[i];
         } else if constexpr (MODE == GEN_STD) {
             const int t = clampi3(acc[0][i], -131072, 131071) + clampi3(acc[1][i], -131072, 131071) +
                           clampi3(acc[2][i], -131072, 131071) + clampi3(acc[3][i], -131072, 131071);
@@ -302,9 +306,9 @@ __device__ __forceinline__ void emit_rows4(const int s4[4][4], const ConvArgs &a
 // ------------------------------------------------------------------ hidden 3x3, 16 -> 16 channels
 template <int MODE, int EPI>
 __global__ __launch_bounds__(256) void mfma_h3_kernel(const ConvArgs a) {
-    constexpr bool GENERAL = MODE != MERGED;
+    constexpr bool GENERAL = MODE == GEN_STD || MODE == GEN_ANY;
     constexpr int SW = MTW + 4;                      // 1 left halo + 64 + 1 right halo + over-read
-    constexpr int SH = MTH + 2 + (GENERAL ? 1 : 0);  // general reads row y+3 with zero weights
+    constexpr int SH = MTH + 2 + (MODE != MERGED ? 1 : 0);  // per-PE chains read row y+3 with zero weights
     __shared__ int4 buf0[SH * SW], buf1[SH * SW];
     const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, n = l & 15, g = l >> 4;
     const int x0 = blockIdx.x * MTW, n_img = blockIdx.z;
@@ -315,13 +319,18 @@ __global__ __launch_bounds__(256) void mfma_h3_kernel(const ConvArgs a) {
     v4i A[GENERAL ? 4 : 3];
 #pragma unroll
     for (int f = 0; f < (GENERAL ? 4 : 3); ++f) A[f] = ld_frag(fr + 4 + f * 64 + l);
+    v4i AR = {0, 0, 0, 0};
+    if constexpr (MODE == HYB) AR = ld_frag(a.afrag2 + 4 + a.risky_pe * 64 + l);
     const float zlo = a.relu ? fmaxf(a.z_next, -128.f) : -128.f;
     const int gx = x0 + 16 * w + n;
     auto compute = [&](const int4 *tile, int y0) __attribute__((always_inline)) {
         const RowIO io = make_rowio(a, n_img, y0, gx, g);
         if constexpr (!GENERAL) {
             const int col = 16 * w + n + g;
-            const v4i acc0 = {ac.x, ac.y, ac.z, ac.w};
+            const v4i zero = {0, 0, 0, 0};
+            const v4i acc0 = (MODE == HYB) ? zero : (v4i){ac.x, ac.y, ac.z, ac.w};
+            const int *t32 = reinterpret_cast<const int *>(tile);
+            const int rbase = (g * SW + 16 * w + n) * 4 + a.risky_pe;      // HYB: word risky_pe of pixel (row g, col)
             v4i B0 = ld_frag(tile + col), B1 = ld_frag(tile + SW + col);
 #pragma unroll
             for (int y4 = 0; y4 < MTH; y4 += 4) {
@@ -329,12 +338,17 @@ __global__ __launch_bounds__(256) void mfma_h3_kernel(const ConvArgs a) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const v4i B2 = ld_frag(tile + (y4 + r + 2) * SW + col);
-                    v4i acc[1];
+                    v4i acc[MODE == HYB ? 2 : 1];
                     acc[0] = mfma(A[0], B0, acc0);
                     acc[0] = mfma(A[1], B1, acc[0]);
                     acc[0] = mfma(A[2], B2, acc[0]);
                     B0 = B1; B1 = B2;
-                    finish_sums<MERGED>(s4[r], acc, ac, a);
+                    if constexpr (MODE == HYB) {
+                        const int o = rbase + (y4 + r) * SW * 4;
+                        const v4i br = {t32[o], t32[o + 4], t32[o + 8], t32[o + 12]};
+                        acc[1] = mfma(AR, br, zero);
+                    }
+                    finish_sums<MODE>(s4[r], acc, ac, a);
                 }
                 emit_rows4<EPI, false, BIASED>(s4, a, io, y4, zlo);
             }
@@ -368,7 +382,7 @@ __global__ __launch_bounds__(256) void mfma_h3_kernel(const ConvArgs a) {
 // ------------------------------------------------------------------ 5x5, 16 input channels
 template <int MODE, int EPI>
 __global__ __launch_bounds__(256) void mfma_h5_kernel(const ConvArgs a) {
-    constexpr bool GENERAL = MODE != MERGED;
+    constexpr bool GENERAL = MODE == GEN_STD || MODE == GEN_ANY;
     constexpr int SW = MTW + 8;          // 2 + 64 + 2 halo, + over-read of the kx = 4..7 group
     constexpr int SH = MTH + 4;
     __shared__ int4 buf0[SH * SW], buf1[SH * SW];
@@ -392,12 +406,20 @@ __global__ __launch_bounds__(256) void mfma_h5_kernel(const ConvArgs a) {
     for (int i = 0; i < 4; ++i) off1[i] = (g == 0) ? 4 * SW + i : (g == 1 ? i * SW + 4 : 4 * SW + 4);
     LastStore ls;
     if constexpr (EPI == EPI_LAST) ls.init(a, n_img, g, gx);
+    v4i AR[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
+    if constexpr (MODE == HYB) {
+        AR[0] = ld_frag(a.afrag2 + 4 + (0 * 4 + a.risky_pe) * 64 + l);
+        AR[1] = ld_frag(a.afrag2 + 4 + (1 * 4 + a.risky_pe) * 64 + l);
+    }
     auto compute = [&](const int4 *tile, int y0) __attribute__((always_inline)) {
         RowIO io;
         if constexpr (EPI != EPI_LAST) io = make_rowio(a, n_img, y0, gx, g);
         if constexpr (!GENERAL) {
             const int col = 16 * w + n + g;
-            const v4i acc0 = {ac.x, ac.y, ac.z, ac.w};
+            const v4i zero = {0, 0, 0, 0};
+            const v4i acc0 = (MODE == HYB) ? zero : (v4i){ac.x, ac.y, ac.z, ac.w};
+            const int *t32 = reinterpret_cast<const int *>(tile);
+            const int cb = (16 * w + n) * 4 + a.risky_pe;       // HYB: word risky_pe of column (16w + n), row 0
             v4i B[5][2];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -412,14 +434,22 @@ __global__ __launch_bounds__(256) void mfma_h5_kernel(const ConvArgs a) {
                     const int y = y4 + r;
                     B[(y + 4) % 5][0] = ld_frag(tile + (y + 4) * SW + col);
                     B[(y + 4) % 5][1] = ld_frag(tile + (y + 4) * SW + col + 4);
-                    v4i acc[1];
+                    v4i acc[MODE == HYB ? 2 : 1];
                     acc[0] = acc0;
 #pragma unroll
                     for (int ky = 0; ky < 5; ++ky) {
                         acc[0] = mfma(A[ky * 2 + 0], B[(y + ky) % 5][0], acc[0]);
                         acc[0] = mfma(A[ky * 2 + 1], B[(y + ky) % 5][1], acc[0]);
                     }
-                    finish_sums<MERGED>(s4[r], acc, ac, a);
+                    if constexpr (MODE == HYB) {
+                        const int o0 = cb + (y + g) * SW * 4;          // K-chunk 0: row y+g, columns +0..3
+                        const v4i b0 = {t32[o0], t32[o0 + 4], t32[o0 + 8], t32[o0 + 12]};
+                        const int ob = cb + y * SW * 4;                // K-chunk 1: per-lane tap offsets off1[]
+                        const v4i b1 = {t32[ob + off1[0] * 4], t32[ob + off1[1] * 4], t32[ob + off1[2] * 4], t32[ob + off1[3] * 4]};
+                        acc[1] = mfma(AR[0], b0, zero);
+                        acc[1] = mfma(AR[1], b1, acc[1]);
+                    }
+                    finish_sums<MODE>(s4[r], acc, ac, a);
                     if constexpr (EPI == EPI_LAST) {
                         if (y0 + y < a.H) ls.store<BIASED>(s4[r], a, y0 + y, zlo);
                     }
@@ -547,7 +577,7 @@ struct StageFrame {
 
 template <int MODE, int SRC, bool RC>
 __global__ __launch_bounds__(256) void mfma_f5_kernel(const ConvArgs a) {
-    constexpr bool GENERAL = MODE != MERGED;
+    constexpr bool GENERAL = MODE == GEN_STD || MODE == GEN_ANY;
     constexpr int SH = MTH + 4;
     constexpr int SWP = MTW + 8;         // staged pixel columns (2 halo + 64 + 2 halo + over-read)
     constexpr int SU = SWP / 4;          // 16-byte units per row per copy
@@ -565,6 +595,11 @@ __global__ __launch_bounds__(256) void mfma_f5_kernel(const ConvArgs a) {
     for (int f = 0; f < 3; ++f)
 #pragma unroll
         for (int p = 0; p < NPE; ++p) A[f][p] = ld_frag(fr + 4 + (f * NPE + p) * 64 + l);
+    v4i AR[3] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+    if constexpr (MODE == HYB) {
+#pragma unroll
+        for (int f = 0; f < 3; ++f) AR[f] = ld_frag(a.afrag2 + 4 + (f * 4 + a.risky_pe) * 64 + l);
+    }
     // lane group -> (kernel row, 4-pixel segment) per K-chunk; must match pack_mfma_frags (MFMA_F5)
     //   f0: (g,0)      f1: (4,0) (0,1) (1,1) (2,1)      f2: (3,1) (4,1) - -
     int addr[3];
@@ -589,9 +624,9 @@ __global__ __launch_bounds__(256) void mfma_f5_kernel(const ConvArgs a) {
             for (int r = 0; r < 4; ++r) {
                 const int y = y4 + r;
                 const v4i B0 = ld_frag(cp + addr[0] + y * SU), B1 = ld_frag(cp + addr[1] + y * SU), B2 = ld_frag(cp + addr[2] + y * SU);
-                v4i acc[GENERAL ? 4 : 1];
+                v4i acc[GENERAL ? 4 : (MODE == HYB ? 2 : 1)];
+                const v4i zero = {0, 0, 0, 0};
                 if constexpr (GENERAL) {
-                    const v4i zero = {0, 0, 0, 0};
 #pragma unroll
                     for (int p = 0; p < 4; ++p) {
                         acc[p] = mfma(A[0][p], B0, zero);
@@ -599,10 +634,15 @@ __global__ __launch_bounds__(256) void mfma_f5_kernel(const ConvArgs a) {
                         acc[p] = mfma(A[2][p], B2, acc[p]);
                     }
                 } else {
-                    const v4i acc0 = {ac.x, ac.y, ac.z, ac.w};
+                    const v4i acc0 = (MODE == HYB) ? zero : (v4i){ac.x, ac.y, ac.z, ac.w};
                     acc[0] = mfma(A[0][0], B0, acc0);
                     acc[0] = mfma(A[1][0], B1, acc[0]);
                     acc[0] = mfma(A[2][0], B2, acc[0]);
+                    if constexpr (MODE == HYB) {       // same B operands, A masked to the risky PE's channel
+                        acc[1] = mfma(AR[0], B0, zero);
+                        acc[1] = mfma(AR[1], B1, acc[1]);
+                        acc[1] = mfma(AR[2], B2, acc[1]);
+                    }
                 }
                 finish_sums<MODE>(s4[r], acc, ac, a);
                 if (a.dbg_q0 && g == 0 && y0 + y < a.H && gx < a.W) {
@@ -653,7 +693,8 @@ static void launch(K kern, ConvArgs a, hipStream_t st) {
         blocks_per_cu = it->second;
     }
     const int strips = (a.W + MTW - 1) / MTW, row_tiles = (a.H + MTH - 1) / MTH;
-    long long k = ((long long)blocks_per_cu * num_cu) / ((long long)strips * a.N);
+    static const int frac_pct = getenv("SESRQ_GRID_PCT") ? atoi(getenv("SESRQ_GRID_PCT")) : 100;   // experiment knob
+    long long k = ((long long)blocks_per_cu * num_cu * frac_pct / 100) / ((long long)strips * a.N);
     k = std::max(1LL, std::min<long long>(k, row_tiles));
     a.chunk_tiles = (int)((row_tiles + k - 1) / k);
     dim3 grid(strips, (row_tiles + a.chunk_tiles - 1) / a.chunk_tiles, a.N);
@@ -664,10 +705,11 @@ static void launch(K kern, ConvArgs a, hipStream_t st) {
     do {                                                                                 \
         if (mode == MERGED) launch(KERN<MERGED, __VA_ARGS__>, a, st);                    \
         else if (mode == GEN_STD) launch(KERN<GEN_STD, __VA_ARGS__>, a, st);             \
+        else if (mode == HYB) launch(KERN<HYB, __VA_ARGS__>, a, st);                     \
         else launch(KERN<GEN_ANY, __VA_ARGS__>, a, st);                                  \
     } while (0)
 
-int launch_mfma(const LayerPlan &lp, const ConvArgs &a_in, int src, int epi, bool general, hipStream_t st) {
+int launch_mfma(const LayerPlan &lp, const ConvArgs &a_in, int src, int epi, bool general, hipStream_t st, bool one_risky_pe) {
     ConvArgs a = a_in;
 #ifdef SESRQ_STAMPS
     if (!g_stampbuf) { (void)hipMalloc((void **)&g_stampbuf, 1 << 22); (void)hipMemset(g_stampbuf, 0, 1 << 22); }
@@ -675,7 +717,7 @@ int launch_mfma(const LayerPlan &lp, const ConvArgs &a_in, int src, int epi, boo
 #endif
     if ((size_t)a.H * a.W * 16 >= ((size_t)1 << 28)) { set_error("mfma: frame too large for 32-bit buffer offsets (H*W must stay below 2^24 pixels)"); return 1; }
     const bool std_bits = a.acc_lo == -131072 && a.acc_hi == 131071 && a.add_lo == -524288 && a.add_hi == 524287;
-    const int mode = !general ? MERGED : (std_bits ? GEN_STD : GEN_ANY);
+    const int mode = !general ? MERGED : (std_bits ? (one_risky_pe ? HYB : GEN_STD) : GEN_ANY);
     switch (lp.mfma_kind) {
         case MFMA_H3:
             if (epi == EPI_MID) SESRQ_BY_MODE(mfma_h3_kernel, EPI_MID);

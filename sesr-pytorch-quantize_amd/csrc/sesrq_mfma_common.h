@@ -12,7 +12,7 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 constexpr float MAGIC = 12582912.f;   // 1.5 * 2^23
 
 // accumulate modes
-enum { MERGED = 0, GEN_STD = 1, GEN_ANY = 2 };   // GEN_STD: 18/20-bit clamps as literals
+enum { MERGED = 0, GEN_STD = 1, GEN_ANY = 2, HYB = 3 };   // GEN_STD: 18/20-bit clamps as literals; HYB: one risky PE
 
 __device__ __forceinline__ v4i mfma(v4i a, v4i b, v4i c) { return __builtin_amdgcn_mfma_i32_16x16x64_i8(a, b, c, 0, 0, 0); }
 __device__ __forceinline__ float med3(float v, float lo, float hi) { return __builtin_amdgcn_fmed3f(v, lo, hi); }

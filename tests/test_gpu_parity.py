@@ -217,3 +217,28 @@ def test_fast_division_is_proven_and_equals_exact_division():
     for tag in ("sesr_x4", "nrdm_3", "sesr_x2_rand"):
         fx, meta, gnet, gx = fixture_case(os.path.join(os.path.dirname(STAGE_FILES[0]), f"{tag}.crop.npz"))
         assert sesrq.Engine(bundle_from_oracle(gnet), _dev()).fast_division_proven(), tag
+
+
+@pytest.mark.parametrize("layer", [0, 1, 3, 4])
+def test_hybrid_single_risky_pe(layer):
+    """Exactly one PE of a layer can saturate -> merged chain + that PE's chain ('hybrid' kernels).  The
+    weights of one (oc, PE) pair are blown up so that the 18-bit clamp really fires."""
+    net = O.synth_net("sesr_x2", 7)
+    w = (net.layers[layer].wq.astype(np.int32) // 2).astype(np.int8)     # keep the other three PEs provably safe
+    pe = 2 if layer == 0 else 1
+    w[5 % w.shape[0], pe::4, :, :] = 127
+    w[7 % w.shape[0], pe::4, :, :] = -128
+    net.layers[layer].wq = w
+    e = sesrq.Engine(bundle_from_oracle(net), _dev(), engine=_lib.ENGINE_MFMA)
+    assert "hybrid" in e.layer_engines()[layer], e.layer_engines()
+    x = rand_frame((2, 3, 41, 77), 21)
+    x[0, :, :20] = 1.0                       # bright region: large positive PE sums
+    want = O.forward(net, x, keep=False)
+    q, y = e.forward(torch.from_numpy(x).to(_dev()))
+    _cmp("q_out", q, want["q_out"])
+    st = O.forward(net, x[:1], keep=True)
+    pe_out = st[f"pe_out{layer}"]
+    assert (np.abs(pe_out) >= 131071).any(), "test net does not reach the 18-bit clamp"
+    e2 = sesrq.Engine(bundle_from_oracle(net), _dev(), engine=_lib.ENGINE_MFMA, force_general=True)
+    q2, _ = e2.forward(torch.from_numpy(x).to(_dev()))
+    assert torch.equal(q, q2)
