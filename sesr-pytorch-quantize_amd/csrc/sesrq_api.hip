@@ -296,14 +296,15 @@ int sesrq_set_option(sesrq_net *net, int option, int value) {
 }
 
 static bool use_fused(const sesrq_net *net, int in_dtype, const sesrq_taps *taps) {
-    return net->fused_ok && (net->engine == SESRQ_ENGINE_AUTO || net->engine == SESRQ_ENGINE_FUSED) && in_dtype == SESRQ_F32 && !taps;
+    // opt-in only: correct, but slower than the per-layer MFMA kernels this round
+    return net->fused_ok && net->engine == SESRQ_ENGINE_FUSED && in_dtype == SESRQ_F32 && !taps;
 }
 
 int sesrq_fast_division_proven(const sesrq_net *net) { return net ? net->fd.ok : 0; }
 
 const char *sesrq_layer_engine(const sesrq_net *net, int k) {
     if (!net || k < 0 || k >= net->L) return "";
-    if (net->fused_ok && (net->engine == SESRQ_ENGINE_AUTO || net->engine == SESRQ_ENGINE_FUSED)) {
+    if (net->fused_ok && net->engine == SESRQ_ENGINE_FUSED) {
         static thread_local std::string s;
         const bool gen = net->layers[k].general || net->force_general;
         s = std::string("fused5-") + (gen ? "general" : "merged");

@@ -185,10 +185,10 @@ __global__ __launch_bounds__(256, 2) void fused5_kernel(const FusedArgs a) {
         } else {
             const int4 *row = rin + slot(r - 1 + g, din) * PA + u0 + n + 1;
             const int4 P0 = row[0], P1 = row[1], P2 = row[2], P3 = row[3];
-            { const v4i b = {P0.x, P1.x, P2.x, P3.x}; acc[0] = mfma(AH[hl][0], b, zero4); }
-            { const v4i b = {P0.y, P1.y, P2.y, P3.y}; acc[1] = mfma(AH[hl][1], b, zero4); }
-            { const v4i b = {P0.z, P1.z, P2.z, P3.z}; acc[2] = mfma(AH[hl][2], b, zero4); }
-            { const v4i b = {P0.w, P1.w, P2.w, P3.w}; acc[3] = mfma(AH[hl][3], b, zero4); }
+            { const v4i b = gather4<0>(P0, P1, P2, P3); acc[0] = mfma(AH[hl][0], b, zero4); }
+            { const v4i b = gather4<1>(P0, P1, P2, P3); acc[1] = mfma(AH[hl][1], b, zero4); }
+            { const v4i b = gather4<2>(P0, P1, P2, P3); acc[2] = mfma(AH[hl][2], b, zero4); }
+            { const v4i b = gather4<3>(P0, P1, P2, P3); acc[3] = mfma(AH[hl][3], b, zero4); }
         }
         int s[4];
         sums<MH>(s, acc, acH[hl]);
@@ -233,19 +233,19 @@ __global__ __launch_bounds__(256, 2) void fused5_kernel(const FusedArgs a) {
             {
                 const int4 *row = ring4 + slot(ro - 2 + g, D4) * PA + u0 + n;
                 const int4 P0 = row[0], P1 = row[1], P2 = row[2], P3 = row[3];
-                { const v4i b = {P0.x, P1.x, P2.x, P3.x}; acc[0] = mfma(A4[0], b, zero4); }
-                { const v4i b = {P0.y, P1.y, P2.y, P3.y}; acc[1] = mfma(A4[1], b, zero4); }
-                { const v4i b = {P0.z, P1.z, P2.z, P3.z}; acc[2] = mfma(A4[2], b, zero4); }
-                { const v4i b = {P0.w, P1.w, P2.w, P3.w}; acc[3] = mfma(A4[3], b, zero4); }
+                { const v4i b = gather4<0>(P0, P1, P2, P3); acc[0] = mfma(A4[0], b, zero4); }
+                { const v4i b = gather4<1>(P0, P1, P2, P3); acc[1] = mfma(A4[1], b, zero4); }
+                { const v4i b = gather4<2>(P0, P1, P2, P3); acc[2] = mfma(A4[2], b, zero4); }
+                { const v4i b = gather4<3>(P0, P1, P2, P3); acc[3] = mfma(A4[3], b, zero4); }
             }
             {
                 int4 P[4];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) P[i] = ring4[slot(ro - 2 + l4_dr[i], D4) * PA + u0 + n + l4_dc[i]];
-                { const v4i b = {P[0].x, P[1].x, P[2].x, P[3].x}; acc[0] = mfma(A4[4], b, acc[0]); }
-                { const v4i b = {P[0].y, P[1].y, P[2].y, P[3].y}; acc[1] = mfma(A4[5], b, acc[1]); }
-                { const v4i b = {P[0].z, P[1].z, P[2].z, P[3].z}; acc[2] = mfma(A4[6], b, acc[2]); }
-                { const v4i b = {P[0].w, P[1].w, P[2].w, P[3].w}; acc[3] = mfma(A4[7], b, acc[3]); }
+                { const v4i b = gather4<0>(P[0], P[1], P[2], P[3]); acc[0] = mfma(A4[4], b, acc[0]); }
+                { const v4i b = gather4<1>(P[0], P[1], P[2], P[3]); acc[1] = mfma(A4[5], b, acc[1]); }
+                { const v4i b = gather4<2>(P[0], P[1], P[2], P[3]); acc[2] = mfma(A4[6], b, acc[2]); }
+                { const v4i b = gather4<3>(P[0], P[1], P[2], P[3]); acc[3] = mfma(A4[7], b, acc[3]); }
             }
         }
         int s[4];

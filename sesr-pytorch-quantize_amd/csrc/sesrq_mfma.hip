@@ -363,10 +363,10 @@ __global__ __launch_bounds__(256) void mfma_h3_kernel(const ConvArgs a) {
                     const int4 P0 = row[0], P1 = row[1], P2 = row[2], P3 = row[3];
                     const v4i zero = {0, 0, 0, 0};
                     v4i acc[4];
-                    { const v4i b = {P0.x, P1.x, P2.x, P3.x}; acc[0] = mfma(A[0], b, zero); }
-                    { const v4i b = {P0.y, P1.y, P2.y, P3.y}; acc[1] = mfma(A[1], b, zero); }
-                    { const v4i b = {P0.z, P1.z, P2.z, P3.z}; acc[2] = mfma(A[2], b, zero); }
-                    { const v4i b = {P0.w, P1.w, P2.w, P3.w}; acc[3] = mfma(A[3], b, zero); }
+                    { const v4i b = gather4<0>(P0, P1, P2, P3); acc[0] = mfma(A[0], b, zero); }
+                    { const v4i b = gather4<1>(P0, P1, P2, P3); acc[1] = mfma(A[1], b, zero); }
+                    { const v4i b = gather4<2>(P0, P1, P2, P3); acc[2] = mfma(A[2], b, zero); }
+                    { const v4i b = gather4<3>(P0, P1, P2, P3); acc[3] = mfma(A[3], b, zero); }
                     finish_sums<MODE>(s4[r], acc, ac, a);
                 }
                 emit_rows4<EPI, false, BIASED>(s4, a, io, y4, zlo);
@@ -469,18 +469,18 @@ __global__ __launch_bounds__(256) void mfma_h5_kernel(const ConvArgs a) {
                     {
                         const int4 *row = tile + (y + g) * SW + col;
                         const int4 P0 = row[0], P1 = row[1], P2 = row[2], P3 = row[3];
-                        { const v4i b = {P0.x, P1.x, P2.x, P3.x}; acc[0] = mfma(A[0], b, zero); }
-                        { const v4i b = {P0.y, P1.y, P2.y, P3.y}; acc[1] = mfma(A[1], b, zero); }
-                        { const v4i b = {P0.z, P1.z, P2.z, P3.z}; acc[2] = mfma(A[2], b, zero); }
-                        { const v4i b = {P0.w, P1.w, P2.w, P3.w}; acc[3] = mfma(A[3], b, zero); }
+                        { const v4i b = gather4<0>(P0, P1, P2, P3); acc[0] = mfma(A[0], b, zero); }
+                        { const v4i b = gather4<1>(P0, P1, P2, P3); acc[1] = mfma(A[1], b, zero); }
+                        { const v4i b = gather4<2>(P0, P1, P2, P3); acc[2] = mfma(A[2], b, zero); }
+                        { const v4i b = gather4<3>(P0, P1, P2, P3); acc[3] = mfma(A[3], b, zero); }
                     }
                     {
                         const int4 *base = tile + y * SW + col;
                         const int4 P0 = base[off1[0]], P1 = base[off1[1]], P2 = base[off1[2]], P3 = base[off1[3]];
-                        { const v4i b = {P0.x, P1.x, P2.x, P3.x}; acc[0] = mfma(A[4], b, acc[0]); }
-                        { const v4i b = {P0.y, P1.y, P2.y, P3.y}; acc[1] = mfma(A[5], b, acc[1]); }
-                        { const v4i b = {P0.z, P1.z, P2.z, P3.z}; acc[2] = mfma(A[6], b, acc[2]); }
-                        { const v4i b = {P0.w, P1.w, P2.w, P3.w}; acc[3] = mfma(A[7], b, acc[3]); }
+                        { const v4i b = gather4<0>(P0, P1, P2, P3); acc[0] = mfma(A[4], b, acc[0]); }
+                        { const v4i b = gather4<1>(P0, P1, P2, P3); acc[1] = mfma(A[5], b, acc[1]); }
+                        { const v4i b = gather4<2>(P0, P1, P2, P3); acc[2] = mfma(A[6], b, acc[2]); }
+                        { const v4i b = gather4<3>(P0, P1, P2, P3); acc[3] = mfma(A[7], b, acc[3]); }
                     }
                     finish_sums<MODE>(s4[r], acc, ac, a);
                     if constexpr (EPI == EPI_LAST) {
@@ -499,9 +499,9 @@ __global__ __launch_bounds__(256) void mfma_h5_kernel(const ConvArgs a) {
 
 // ------------------------------------------------------------------ first layer 5x5, IC <= 4
 // The frame is quantised while it is staged (q0 = clamp8(rint(x/s0 + z0)), quan_func.py:225);
-// a pixel is one dword (byte c = channel c).  A lane's 16 bytes = 4 horizontally adjacent
-// pixels, which start at an arbitrary pixel column -> the tile is kept in 4 copies shifted by
-// 0..3 pixels so that every such group is one aligned ds_read_b128.
+// a pixel is one dword (byte c = channel c).  A lane's 16 bytes = 4 horizontally adjacent pixels
+// starting at an arbitrary pixel column: read as dwords (ds_read2_b32 pairs), which have no 16-byte
+// alignment requirement -- one copy of the tile in LDS, one ds_write_b32 per staged pixel.
 template <int SRC, int SH, int SWP>
 struct StageFrame {
     static constexpr int NIT = (SH * SWP + 255) / 256;
@@ -538,10 +538,12 @@ struct StageFrame {
             const int vo = FIRST ? (ok[it] ? voff[it] + soff : (int)0x80000000) : voff[it];
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
-                // channel planes beyond ic: the whole load is pushed out of range (returns 0, masked below)
-                const int so = (c < a.ic) ? (FIRST ? 0 : soff) + c * plane_bytes : (int)0x7fffff00;
-                if constexpr (SRC == SRC_F32) raw[it][c] = __builtin_amdgcn_raw_buffer_load_b32(rs, vo, so, 0);
-                else raw[it][c] = (unsigned)(int)(signed char)__builtin_amdgcn_raw_buffer_load_b8(rs, vo, so, 0);
+                raw[it][c] = 0;
+                if (c < a.ic) {            // wave-uniform: channel planes beyond ic are not loaded at all
+                    const int so = (FIRST ? 0 : soff) + c * plane_bytes;
+                    if constexpr (SRC == SRC_F32) raw[it][c] = __builtin_amdgcn_raw_buffer_load_b32(rs, vo, so, 0);
+                    else raw[it][c] = (unsigned)(int)(signed char)__builtin_amdgcn_raw_buffer_load_b8(rs, vo, so, 0);
+                }
             }
         }
     }
@@ -552,7 +554,6 @@ struct StageFrame {
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
             const int i = tid + it * 256;
-            const int ty = i / SWP, tx = i - ty * SWP;
             int word = 0;
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
@@ -564,13 +565,7 @@ struct StageFrame {
                 if (c < a.ic) word |= (q & 0xff) << (8 * c);
             }
             if (!ok[it]) word = a.pad_word;
-            if (i < SH * SWP) {
-#pragma unroll
-                for (int s = 0; s < 4; ++s) {
-                    const int t = tx - s;
-                    if (t >= 0) cpw[((s * SH + ty) * SU + (t >> 2)) * 4 + (t & 3)] = word;
-                }
-            }
+            if (i < SH * SWP) cpw[i] = word;
         }
     }
 };
@@ -581,7 +576,7 @@ __global__ __launch_bounds__(256) void mfma_f5_kernel(const ConvArgs a) {
     constexpr int SH = MTH + 4;
     constexpr int SWP = MTW + 8;         // staged pixel columns (2 halo + 64 + 2 halo + over-read)
     constexpr int SU = SWP / 4;          // 16-byte units per row per copy
-    __shared__ int4 buf0[4 * SH * SU], buf1[4 * SH * SU];
+    __shared__ int4 buf0[SH * SU], buf1[SH * SU];      // SH x SWP pixels of 4 bytes
     const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, n = l & 15, g = l >> 4;
     const int x0 = blockIdx.x * MTW, n_img = blockIdx.z;
     const size_t HW = (size_t)a.H * a.W;
@@ -608,8 +603,7 @@ __global__ __launch_bounds__(256) void mfma_f5_kernel(const ConvArgs a) {
         const int seg[3] = {0, g == 0 ? 0 : 1, g < 2 ? 1 : 0};
 #pragma unroll
         for (int f = 0; f < 3; ++f) {
-            const int c0 = 16 * w + n + 4 * seg[f];
-            addr[f] = ((c0 & 3) * SH + rowofs[f]) * SU + (c0 >> 2);
+            addr[f] = rowofs[f] * SWP + 16 * w + n + 4 * seg[f];      // first of the 4 pixels, in pixels
         }
     }
     const float zlo = a.relu ? fmaxf(a.z_next, -128.f) : -128.f;
@@ -623,7 +617,8 @@ __global__ __launch_bounds__(256) void mfma_f5_kernel(const ConvArgs a) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int y = y4 + r;
-                const v4i B0 = ld_frag(cp + addr[0] + y * SU), B1 = ld_frag(cp + addr[1] + y * SU), B2 = ld_frag(cp + addr[2] + y * SU);
+                const int *p0 = cpw + addr[0] + y * SWP, *p1 = cpw + addr[1] + y * SWP, *p2 = cpw + addr[2] + y * SWP;
+                const v4i B0 = {p0[0], p0[1], p0[2], p0[3]}, B1 = {p1[0], p1[1], p1[2], p1[3]}, B2 = {p2[0], p2[1], p2[2], p2[3]};
                 v4i acc[GENERAL ? 4 : (MODE == HYB ? 2 : 1)];
                 const v4i zero = {0, 0, 0, 0};
                 if constexpr (GENERAL) {
@@ -646,7 +641,7 @@ __global__ __launch_bounds__(256) void mfma_f5_kernel(const ConvArgs a) {
                 }
                 finish_sums<MODE>(s4[r], acc, ac, a);
                 if (a.dbg_q0 && g == 0 && y0 + y < a.H && gx < a.W) {
-                    const int word = cpw[((0 * SH + y + 2) * SU + ((16 * w + n + 2) >> 2)) * 4 + ((16 * w + n + 2) & 3)];
+                    const int word = cpw[(y + 2) * SWP + 16 * w + n + 2];
                     for (int c = 0; c < a.ic; ++c)
                         a.dbg_q0[((size_t)n_img * a.ic + c) * HW + (size_t)(y0 + y) * a.W + gx] = (signed char)((word >> (8 * c)) & 0xff);
                 }

@@ -33,6 +33,27 @@ __device__ __forceinline__ float quantize_in(float x, float s, float z, const Fa
     return med3(rintf(__fadd_rn(t, z)), -128.f, 127.f);
 }
 
+// general path: the MFMA operand of PE P = word P of four staged pixels.  Two v_pk_mov_b32 build the
+// four consecutive operand registers (each moves one word out of two different source pairs) instead of
+// four v_mov_b32.  op_sel/op_sel_hi = [s,s]: D.lo = src0.{lo|hi}, D.hi = src1.{lo|hi} (checked on gfx950).
+typedef int v2i __attribute__((ext_vector_type(2)));
+template <int P>
+__device__ __forceinline__ v4i gather4(const int4 a, const int4 b, const int4 c, const int4 d) {
+    const int av[4] = {a.x, a.y, a.z, a.w}, bv[4] = {b.x, b.y, b.z, b.w}, cv[4] = {c.x, c.y, c.z, c.w}, dv[4] = {d.x, d.y, d.z, d.w};
+    constexpr int h = 2 * (P / 2);
+    const v2i pa = {av[h], av[h + 1]}, pb = {bv[h], bv[h + 1]}, pc = {cv[h], cv[h + 1]}, pd = {dv[h], dv[h + 1]};
+    v2i lo, hi;
+    if constexpr ((P & 1) == 0) {
+        asm("v_pk_mov_b32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,0]" : "=v"(lo) : "v"(pa), "v"(pb));
+        asm("v_pk_mov_b32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,0]" : "=v"(hi) : "v"(pc), "v"(pd));
+    } else {
+        asm("v_pk_mov_b32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[1,1]" : "=v"(lo) : "v"(pa), "v"(pb));
+        asm("v_pk_mov_b32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[1,1]" : "=v"(hi) : "v"(pc), "v"(pd));
+    }
+    const v4i r = {lo[0], lo[1], hi[0], hi[1]};
+    return r;
+}
+
 // low bytes of four words -> one word
 __device__ __forceinline__ unsigned pack_lo_bytes(unsigned y0, unsigned y1, unsigned y2, unsigned y3) {
     const unsigned w01 = __builtin_amdgcn_perm(y1, y0, 0x0c0c0400u);

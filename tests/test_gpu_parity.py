@@ -156,7 +156,7 @@ def test_full_size_properties_1080p():
     (c) determinism: two runs give identical bytes."""
     net = O.synth_net("sesr_x2", 0)
     e = sesrq.Engine(bundle_from_oracle(net), _dev())
-    assert e.layer_engines()[0].startswith("fused"), "default engine for the reference topology is the fused one"
+    assert all(s.startswith("mfma") for s in e.layer_engines()), "default engine = per-layer MFMA kernels"
     x = torch.from_numpy(rand_frame((1, 3, 1080, 1920), 2)).to(_dev())
     q, y = e.forward(x)
     q2, _ = e.forward(x)
