@@ -52,6 +52,9 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--batch", type=int, default=1, help="frames per step per GPU")
+    ap.add_argument("--streams", type=int, default=3,
+                    help="HIP streams the steps are enqueued on round-robin (frames are independent; each stream has "
+                         "its own workspace and output buffer) -- fills the launch/prologue/tail gaps of the 5 kernels")
     ap.add_argument("--workload", default="sesr_x2_1080p", choices=sorted(WORKLOADS))
     ap.add_argument("--engine", default="auto", choices=["auto", "dot4", "mfma"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -84,10 +87,17 @@ def main():
     B = args.batch
     g = torch.Generator().manual_seed(1 + rank)
     x = torch.rand((B, cin, H, W), generator=g, dtype=torch.float32).to(dev)
-    out_q = torch.empty(eng.out_shape(B, H, W), dtype=torch.int8, device=dev)
+    NS = max(1, args.streams)
+    streams = [torch.cuda.Stream(device=dev) for _ in range(NS)]
+    outs = [torch.empty(eng.out_shape(B, H, W), dtype=torch.int8, device=dev) for _ in range(NS)]
+    out_q = outs[0]
+    torch.cuda.synchronize()
+    counter = [0]
 
     def step():
-        eng.forward(x, want_q=True, want_f=False, out_q=out_q)
+        i = counter[0] % NS
+        counter[0] += 1
+        eng.forward(x, want_q=True, want_f=False, out_q=outs[i], stream=streams[i], slot=i)
 
     def fence():
         grp.barrier()
@@ -113,14 +123,24 @@ def main():
         alg = layer_bytes_per_px(bundle, kdom) * px
         ach = alg / (layer_ms[kdom] * 1e-3)
         total_alg = sum(layer_bytes_per_px(bundle, k) for k in range(bundle.L)) * px
+        # HBM bytes per launch of that kernel from the committed rocprofv3 PMC passes (profiles/): FETCH_SIZE and
+        # WRITE_SIZE in separate runs, FETCH_SIZE doubled for 16-B/lane streaming reads (MI355X_MICROARCH.md, HBM)
+        traffic = None
+        tfile = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+        if os.path.isfile(tfile):
+            tj = json.load(open(tfile))
+            traffic = tj.get(args.workload, {}).get(f"layer{kdom}", {}).get("hbm_bytes_per_launch")
         roofline = {"bound": "hbm", "achieved": round(ach / 1e9, 2), "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                    "frac": round(ach / HBM_PEAK, 4), "traffic": None,
+                    "frac": round(ach / HBM_PEAK, 4), "traffic": traffic,
                     "kernel": f"layer{kdom}:{eng.layer_engines()[kdom]}",
                     "kernel_ms": round(layer_ms[kdom], 5), "algorithmic_bytes_per_launch": alg,
                     "layer_ms": [round(v, 5) for v in layer_ms],
                     "layer_frac": [round(layer_bytes_per_px(bundle, k) * px / (layer_ms[k] * 1e-3) / HBM_PEAK, 4) for k in range(bundle.L)],
                     "forward_device_ms": round(fwd_ms, 5),
-                    "whole_forward_frac": round(total_alg / (fwd_ms * 1e-3) / HBM_PEAK, 4)}
+                    "whole_forward_frac": round(total_alg / (fwd_ms * 1e-3) / HBM_PEAK, 4),
+                    "throughput_frac": round(total_alg * fps / world / HBM_PEAK, 4),
+                    "note": "layer_ms: HIP events around each launch on one stream (sesrq_forward_timed); throughput_frac = "
+                            "algorithmic bytes of a whole forward x frames/s/GPU / peak"}
 
         # ---- parity spot-check against the oracle (checker only): crop with a 7-px halo
         sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -151,7 +171,7 @@ def main():
                   "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                   "ms_per_step": round(elapsed / args.steps * 1e3, 5), "higher_is_better": True, "scaling": "weak",
                   "vs_baseline": None, "dtype": "i8", "data": "synthetic",
-                  "config": {"workload": desc, "name": args.workload, "frames_per_step_per_gpu": B, "in": [B, cin, H, W],
+                  "config": {"workload": desc, "name": args.workload, "frames_per_step_per_gpu": B, "streams": NS, "in": [B, cin, H, W],
                              "out": list(eng.out_shape(B, H, W)), "input_dtype": "f32", "output_dtype": "i8",
                              "weights": f"reference random-init net, calibrated by the reference ({fixture})",
                              "sharding": f"frames x{world}, no collective", "engines": eng.layer_engines()},
