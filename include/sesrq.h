@@ -121,6 +121,30 @@ int sesrq_forward_timed(const sesrq_net *net, const void *in, int in_dtype, void
 /* Name of the kernel family the net resolved to for layer k ("dot4-general", "mfma-merged", ...). */
 const char *sesrq_layer_engine(const sesrq_net *net, int k);
 
+/* ---- calibration pass (the reference's exe_mode 0) ------------------------ */
+
+/* One conv of the calibration forward (reference: quantize_asymmetrical_by_tensor mode 0, quan_func.py:175-215
+ * -> reshape_input_for_hardware_pe -> Conv2d with fake-quantised weights -> PEs_and_bias_adder mode 0,
+ * quan_func.py:330-333,431-434,457-459 -> activation).  All pointers are device pointers. */
+typedef struct sesrq_calib_conv_desc {
+    int32_t k, ic, oc;
+    const int32_t *w;          /* [oc][ic][k][k] quantised weights as int32 */
+    const float *qbias;        /* [oc] clamp16(rint(b/(s*sw))) * f32(s*sw) */
+    float in_scale;            /* f32 of this batch's input scale */
+    int32_t in_zero;           /* this batch's input zero point (may be < -128) */
+    float ss;                  /* f32(in_scale * weight_scale) */
+    float acc_lo, acc_hi;      /* (-2^17 - zero)*s*sw , (2^17-1 - zero)*s*sw */
+    float add_lo, add_hi;      /* same with 2^19 */
+    int32_t relu;
+} sesrq_calib_conv_desc;
+/* out = act(conv) (+ skip, the float long residual added after the activation; may be NULL) */
+int sesrq_calib_conv(const sesrq_calib_conv_desc *d, const float *in, const float *skip, float *out,
+                     int N, int H, int W, void *stream);
+/* min and max of a device fp32 tensor -> out_min_max[0..1] (device); scratch8: 8 bytes of device scratch */
+int sesrq_calib_minmax(const float *x, size_t n, float *out_min_max, void *scratch8, void *stream);
+/* (clamp8(rint(x/scale + zero)) - zero) * scale  (quan_func.py:207,215) */
+int sesrq_calib_fakequant(const float *in, float *out, size_t n, float scale, int zero, void *stream);
+
 /* ---- host scalar code of the path (load time) -------------------------------------- */
 
 /* quan_layer_between_const (myQL/quan_func.py:495-515): r -> (M, n), truncating. */

@@ -10,6 +10,10 @@ Same names, argument meaning and error behaviour as the reference functions they
     PEs_and_bias_adder               quan_func.py:418   per-conv stage
     requan_conv2d_output             quan_func.py:517   per-conv stage
 
+Both execution modes of the reference are covered: exe_mode 1 (integer inference) lowers to
+sesrq_forward, exe_mode 0 (calibration: fake-quant float forward + running min/max, test.py) lowers to
+sesrq.calibrate.Calibrator (sesrq_calib_conv / _minmax / _fakequant).
+
 In the reference every stage is a float32 torch op that hands its parameters to the next stage
 through files under ./output_pt/.  Here the four per-conv stage callables are *markers*: the graph
 splicers (myQL/graph_modify.py) insert them exactly like the reference does, and the spliced
@@ -84,10 +88,6 @@ class _StageMarker:
         self.__module__ = __name__
 
     def __call__(self, *args, **kwargs):
-        if kwargs.get("exe_mode", 1) == 0:
-            raise NotImplementedError(
-                f"{self.__name__}: exe_mode 0 (calibration) is not part of the device path yet; provide "
-                "input.K.scale/zero through sesrq.store.STORE (e.g. STORE.load_output_pt('output_pt'))")
         raise RuntimeError(
             f"{self.__name__} is a stage marker: splice it with myQL.graph_modify and call the spliced model; the "
             "chain runs as one fused device op (there is no per-stage fallback)")

@@ -32,6 +32,12 @@ class NetDesc(C.Structure):
                 ("pe_add_bits", C.c_int32)]
 
 
+class CalibConvDesc(C.Structure):
+    _fields_ = [("k", C.c_int32), ("ic", C.c_int32), ("oc", C.c_int32), ("w", C.c_void_p), ("qbias", C.c_void_p),
+                ("in_scale", C.c_float), ("in_zero", C.c_int32), ("ss", C.c_float), ("acc_lo", C.c_float),
+                ("acc_hi", C.c_float), ("add_lo", C.c_float), ("add_hi", C.c_float), ("relu", C.c_int32)]
+
+
 class Taps(C.Structure):
     _fields_ = [("act", C.c_void_p * MAX_LAYERS), ("pe_out", C.c_void_p * MAX_LAYERS),
                 ("pe_add", C.c_void_p * MAX_LAYERS)]
@@ -52,6 +58,10 @@ SYMBOLS = {
                                       C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_int, C.POINTER(C.c_float),
                                       C.POINTER(C.c_float)]),
     "sesrq_layer_engine": (C.c_char_p, [C.c_void_p, C.c_int]),
+    "sesrq_calib_conv": (C.c_int, [C.POINTER(CalibConvDesc), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                   C.c_void_p]),
+    "sesrq_calib_minmax": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "sesrq_calib_fakequant": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_float, C.c_int, C.c_void_p]),
     "sesrq_requant_const": (C.c_int, [C.c_double, C.c_int, C.c_int, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     "sesrq_quantize_weight": (C.c_int, [C.POINTER(C.c_float), C.c_size_t, C.c_int, C.POINTER(C.c_int8),
                                         C.POINTER(C.c_double)]),

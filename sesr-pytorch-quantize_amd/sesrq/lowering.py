@@ -113,6 +113,43 @@ def lower(gm: torch.fx.GraphModule, store=STORE) -> Bundle:
                                         pe_acc_bits=pe_acc, pe_add_bits=pe_add)
 
 
+def graph_mode(gm: torch.fx.GraphModule) -> int:
+    """exe_mode of the spliced quantiser nodes: 1 = integer inference, 0 = calibration, -1 = none spliced."""
+    for n in gm.graph.nodes:
+        if _fname(n) == _STAGE_ORDER_IN[0]:
+            return int(n.kwargs.get("exe_mode", -1))
+    return -1
+
+
+def lower_calibration(gm: torch.fx.GraphModule, device, store=STORE):
+    """A mode-0 graph (reference test.py:79-106: quantiser before every conv and before PixelShuffle, PE
+    split, bias bypass; float long skip) -> sesrq.calibrate.Calibrator."""
+    from .calibrate import Calibrator
+    modules = dict(gm.named_modules())
+    convs = [n for n in gm.graph.nodes if n.op == "call_module" and type(modules[n.target]) is nn.Conv2d]
+    quantized, biases, widths = [], [], None
+    for k, c in enumerate(convs):
+        r = c.args[0]
+        q = r.args[0] if _fname(r) == _STAGE_ORDER_IN[1] else None
+        if q is None or _fname(q) != _STAGE_ORDER_IN[0] or q.kwargs.get("exe_mode") != 0 or q.kwargs.get("func_id") != k:
+            raise RuntimeError(f"sesrq calibration: conv {k} must be fed by quantize_asymmetrical_by_tensor(exe_mode=0, "
+                               f"func_id={k}) -> reshape_input_for_hardware_pe (test.py:86-100)")
+        pb = _single_user(c)
+        if _fname(pb) != _STAGE_ORDER_OUT[0] or pb.kwargs.get("exe_mode") != 0:
+            raise RuntimeError(f"sesrq calibration: conv {k} must be followed by PEs_and_bias_adder(exe_mode=0)")
+        widths = (int(pb.kwargs["pe_add_width"]), int(pb.kwargs["pe_acc_width"]), int(pb.kwargs["bias_width"]))
+        wq = np.asarray(store[f"weight/conv.weight.{k}"].cpu().numpy() if hasattr(store[f"weight/conv.weight.{k}"], "cpu")
+                        else store[f"weight/conv.weight.{k}"])
+        quantized.append((wq.astype(np.int8), float(store[f"weight/conv.weight.{k}.scale"])))
+        biases.append(np.asarray(pb.kwargs["bias"], dtype=np.float32))
+    ps = 1
+    for n in gm.graph.nodes:
+        if n.op == "call_module" and isinstance(modules[n.target], nn.PixelShuffle):
+            ps = int(modules[n.target].upscale_factor)
+    return Calibrator(None, biases, ps, device, pe_acc_bits=widths[1], pe_add_bits=widths[0], bias_bits=widths[2],
+                      quantized=quantized)
+
+
 class SesrqGraphModule(torch.fx.GraphModule):
     """GraphModule whose forward is the fused device op.  `last_q` keeps the int8 result (input.L.pt
     after PixelShuffle) of the most recent call; the return value is the reference's float tensor."""
@@ -142,6 +179,20 @@ class SesrqGraphModule(torch.fx.GraphModule):
         if not x.is_cuda:
             raise RuntimeError("sesrq: the integer path runs on the GPU only; move the frame to a HIP device "
                                "(model(inps.cuda())) -- there is no CPU fallback")
+        if graph_mode(self) == 0:
+            # calibration forward (reference test.py:146): observe ranges, keep them in the store like the
+            # reference keeps input.K.{min,max}_val / per-batch scale / zero files
+            cal = self.__dict__.get("_sesrq_cal")
+            if cal is None or cal.device != x.device:
+                cal = lower_calibration(self, x.device)
+                self.__dict__["_sesrq_cal"] = cal
+            y = cal.observe(x.float())
+            for k in range(cal.L + 1):
+                STORE[f"input/input.{k}.min_val"] = cal.run_min[k]
+                STORE[f"input/input.{k}.max_val"] = cal.run_max[k]
+                STORE[f"input/input.{k}.scale"] = cal.last_scale[k]
+                STORE[f"input/input.{k}.zero"] = cal.last_zero[k]
+            return y
         eng = self._sesrq_engine(x.device)
         q, y = eng.forward(x.float() if x.dtype != torch.int8 else x)
         self.__dict__["last_q"] = q

@@ -242,3 +242,37 @@ def test_hybrid_single_risky_pe(layer):
     e2 = sesrq.Engine(bundle_from_oracle(net), _dev(), engine=_lib.ENGINE_MFMA, force_general=True)
     q2, _ = e2.forward(torch.from_numpy(x).to(_dev()))
     assert torch.equal(q, q2)
+
+
+@pytest.mark.parametrize("case", ["sesr_x4", "nrdm_3", "sesr_x2_rand"])
+def test_calibration_pass_matches_reference_ranges(case):
+    """exe_mode 0 on the GPU: running min/max of every quantiser input on the reference's own random frame
+    vs the ranges the reference observed (tests/golden/*.params.npz).  fp32 summation order differs from
+    oneDNN's, so the bar is a tolerance (1e-4 of the range), written here; the derived integer bundle must
+    still reproduce the reference's requant constants."""
+    from sesrq.calibrate import Calibrator
+    from conftest import GOLDEN, load_fixture
+    p, pm = load_fixture(os.path.join(GOLDEN, f"{case}.params.npz"))
+    ps = {5: 4, 6: 2, 3: 1}[pm["mflag"]]
+    cal = Calibrator([p[f"Wf{k}"] for k in range(5)], [p[f"bf{k}"] for k in range(5)], ps, _dev())
+    x = np.load(os.path.join(GOLDEN, "rand_SR_Input_80x960.npy" if pm["mflag"] == 5 else "rand_DM_Input_80x960.npy"))
+    y = cal.observe(torch.from_numpy(x).to(_dev()))
+    r = ps
+    assert tuple(y.shape) == (1, p["Wf4"].shape[0] // (r * r), 80 * r, 960 * r)
+    for k in range(6):
+        span = pm["max"][k] - pm["min"][k]
+        assert abs(cal.run_min[k] - pm["min"][k]) <= 1e-4 * span, (k, cal.run_min[k], pm["min"][k])
+        assert abs(cal.run_max[k] - pm["max"][k]) <= 1e-4 * span, (k, cal.run_max[k], pm["max"][k])
+    scale, zero = cal.finalize()
+    assert zero == pm["zero"]
+    np.testing.assert_allclose(scale, pm["scale"], rtol=2e-4)
+    b = cal.bundle()
+    fx, meta = load_fixture(os.path.join(GOLDEN, f"{case}.crop.npz"))
+    for k in range(5):
+        np.testing.assert_array_equal(b.layers[k].wq, fx[f"Wq{k}"])
+        assert b.layers[k].n == meta["n"][k] and abs(b.layers[k].M - meta["M"][k]) <= max(2, meta["M"][k] * 3e-4)
+    # a second frame only widens the ranges; reset() forgets them
+    cal.observe(torch.from_numpy(np.ascontiguousarray(x[:, :, ::-1, :]) * 0.5).to(_dev()))
+    assert all(cal.run_max[k] >= pm["max"][k] * (1 - 1e-4) for k in range(6))
+    cal.reset()
+    assert cal.run_min[0] is None

@@ -78,7 +78,7 @@ def test_error_conventions_of_the_callables():
         qf.reshape_input_for_hardware_pe(torch.zeros(3, 4, 5))
     with pytest.raises(RuntimeError, match="stage marker"):
         qf.requan_conv2d_output(torch.zeros(1, 1, 2, 2), func_id=0, exe_mode=1)
-    with pytest.raises(NotImplementedError, match="calibration"):
+    with pytest.raises(RuntimeError, match="stage marker"):
         qf.quantize_asymmetrical_by_tensor(torch.zeros(1, 1, 2, 2), width=8, exe_mode=0, func_id=0)
     assert qf.float_to_hex(-1, 8) == "ff" and qf.float_to_hex(127, 8) == "7f" and qf.float_to_hex(-131072, 18) == "20000"
 
@@ -122,3 +122,40 @@ def test_spliced_model_forward_is_the_golden_output(case):
     y = model(torch.from_numpy(fx["x"]).cuda())
     np.testing.assert_array_equal(y.cpu().numpy(), fx["out"])
     assert model.last_q.dtype == torch.int8
+
+
+def test_calibration_graph_is_recognised_on_cpu():
+    """mode-0 splice (reference test.py:79-106) is accepted and classified; running it needs the GPU."""
+    import importlib
+    STORE.clear()
+    calib = importlib.import_module("test")            # sesr-pytorch-quantize_amd/test.py, the calibration entry
+    from sesrq.lowering import graph_mode
+    gm = calib.splice_calibration(sim.float_model(5, params=os.path.join(GOLDEN, "sesr_x4.params.npz")))
+    assert graph_mode(gm) == 0
+    names = [getattr(n.target, "__name__", str(n.target)) for n in gm.graph.nodes]
+    assert names.count("quantize_asymmetrical_by_tensor") == 6          # 5 convs + the one before PixelShuffle
+    assert "requan_conv2d_output" not in names
+    with pytest.raises(RuntimeError, match="GPU only"):
+        gm(torch.zeros(1, 1, 8, 8))
+
+
+@pytest.mark.gpu
+def test_calibrate_then_infer_end_to_end():
+    """test.py-equivalent calibration on the reference's random frame, then sim.py-equivalent inference with
+    the calibrated domains: the integer output equals the oracle's for the bundle derived from THIS calibration."""
+    import importlib
+    from oracle import sesrq_oracle as O
+    calib = importlib.import_module("test")
+    frames = os.path.join(GOLDEN, "rand_SR_Input_80x960.npy")
+    scale, zero = calib.main(["--mflag", "5", "--params", os.path.join(GOLDEN, "sesr_x4.params.npz"), "--frames", frames])
+    _, pm = load_fixture(os.path.join(GOLDEN, "sesr_x4.params.npz"))
+    assert zero == pm["zero"]
+    np.testing.assert_allclose(scale, pm["scale"], rtol=2e-4)
+    model = sim.splice(sim.float_model(5, params=os.path.join(GOLDEN, "sesr_x4.params.npz")))
+    STORE.set_activation_domains(scale, zero)          # float_model() put the reference's domains there; use ours
+    b = model.sesrq_bundle()
+    x = np.load(frames)[:, :, :32, :64].copy()
+    y = model(torch.from_numpy(x).cuda())
+    net = O.Net(layers=[O.Layer(l.wq, l.add_const, l.M, l.n, l.relu) for l in b.layers], scale=b.scale, zero=b.zero,
+                M_res=b.M_res, n_res=b.n_res, pixel_shuffle=b.pixel_shuffle)
+    np.testing.assert_array_equal(y.cpu().numpy(), O.forward(net, x)["y"])
