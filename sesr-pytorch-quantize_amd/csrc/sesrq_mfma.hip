@@ -502,10 +502,9 @@ __global__ __launch_bounds__(256) void mfma_h5_kernel(const ConvArgs a) {
 // a pixel is one dword (byte c = channel c).  A lane's 16 bytes = 4 horizontally adjacent pixels
 // starting at an arbitrary pixel column: read as dwords (ds_read2_b32 pairs), which have no 16-byte
 // alignment requirement -- one copy of the tile in LDS, one ds_write_b32 per staged pixel.
-template <int SRC, int SH, int SWP>
+template <int SRC, int SH, int SWP, int PITCH>
 struct StageFrame {
     static constexpr int NIT = (SH * SWP + 255) / 256;
-    static constexpr int SU = SWP / 4;
     static constexpr int ESZ = (SRC == SRC_F32) ? 4 : 1;
     unsigned raw[NIT][4];
     bool ok[NIT];
@@ -565,7 +564,7 @@ struct StageFrame {
                 if (c < a.ic) word |= (q & 0xff) << (8 * c);
             }
             if (!ok[it]) word = a.pad_word;
-            if (i < SH * SWP) cpw[i] = word;
+            if (i < SH * SWP) cpw[(i / SWP) * PITCH + (i % SWP)] = word;
         }
     }
 };
@@ -575,8 +574,9 @@ __global__ __launch_bounds__(256) void mfma_f5_kernel(const ConvArgs a) {
     constexpr bool GENERAL = MODE == GEN_STD || MODE == GEN_ANY;
     constexpr int SH = MTH + 4;
     constexpr int SWP = MTW + 8;         // staged pixel columns (2 halo + 64 + 2 halo + over-read)
-    constexpr int SU = SWP / 4;          // 16-byte units per row per copy
-    __shared__ int4 buf0[SH * SU], buf1[SH * SU];      // SH x SWP pixels of 4 bytes
+    constexpr int PITCH = SWP + 8;       // LDS row pitch in pixels: 16 dwords mod 32, so the four lane groups of an
+                                         // operand read (rows g, g+1, ...) hit disjoint banks
+    __shared__ int4 buf0[SH * PITCH / 4], buf1[SH * PITCH / 4];      // SH rows of 4-byte pixels
     const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, n = l & 15, g = l >> 4;
     const int x0 = blockIdx.x * MTW, n_img = blockIdx.z;
     const size_t HW = (size_t)a.H * a.W;
@@ -603,7 +603,7 @@ __global__ __launch_bounds__(256) void mfma_f5_kernel(const ConvArgs a) {
         const int seg[3] = {0, g == 0 ? 0 : 1, g < 2 ? 1 : 0};
 #pragma unroll
         for (int f = 0; f < 3; ++f) {
-            addr[f] = rowofs[f] * SWP + 16 * w + n + 4 * seg[f];      // first of the 4 pixels, in pixels
+            addr[f] = rowofs[f] * PITCH + 16 * w + n + 4 * seg[f];    // first of the 4 pixels, in pixels
         }
     }
     const float zlo = a.relu ? fmaxf(a.z_next, -128.f) : -128.f;
@@ -617,7 +617,7 @@ __global__ __launch_bounds__(256) void mfma_f5_kernel(const ConvArgs a) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int y = y4 + r;
-                const int *p0 = cpw + addr[0] + y * SWP, *p1 = cpw + addr[1] + y * SWP, *p2 = cpw + addr[2] + y * SWP;
+                const int *p0 = cpw + addr[0] + y * PITCH, *p1 = cpw + addr[1] + y * PITCH, *p2 = cpw + addr[2] + y * PITCH;
                 const v4i B0 = {p0[0], p0[1], p0[2], p0[3]}, B1 = {p1[0], p1[1], p1[2], p1[3]}, B2 = {p2[0], p2[1], p2[2], p2[3]};
                 v4i acc[GENERAL ? 4 : (MODE == HYB ? 2 : 1)];
                 const v4i zero = {0, 0, 0, 0};
@@ -641,7 +641,7 @@ __global__ __launch_bounds__(256) void mfma_f5_kernel(const ConvArgs a) {
                 }
                 finish_sums<MODE>(s4[r], acc, ac, a);
                 if (a.dbg_q0 && g == 0 && y0 + y < a.H && gx < a.W) {
-                    const int word = cpw[(y + 2) * SWP + 16 * w + n + 2];
+                    const int word = cpw[(y + 2) * PITCH + 16 * w + n + 2];
                     for (int c = 0; c < a.ic; ++c)
                         a.dbg_q0[((size_t)n_img * a.ic + c) * HW + (size_t)(y0 + y) * a.W + gx] = (signed char)((word >> (8 * c)) & 0xff);
                 }
@@ -650,7 +650,7 @@ __global__ __launch_bounds__(256) void mfma_f5_kernel(const ConvArgs a) {
         }
     };
 #define SESRQ_COMPUTE(B) compute(B, y0);
-    using Stage = StageFrame<SRC, SH, SWP>;
+    using Stage = StageFrame<SRC, SH, SWP, PITCH>;
     SESRQ_TILE_WALK(Stage, buf0, buf1, SESRQ_COMPUTE)
 #undef SESRQ_COMPUTE
 }

@@ -276,3 +276,38 @@ def test_calibration_pass_matches_reference_ranges(case):
     assert all(cal.run_max[k] >= pm["max"][k] * (1 - 1e-4) for k in range(6))
     cal.reset()
     assert cal.run_min[0] is None
+
+
+def test_config4_shape_batch_of_x4_frames():
+    """BASELINE config 4 per-GPU share: SESR-x4 540p -> 4K, 4 frames in one call.  Frame 0 against the C oracle
+    (full size), the others through batch independence."""
+    from oracle import c_oracle as CO
+    fx, meta, net, _ = fixture_case(os.path.join(os.path.dirname(STAGE_FILES[0]), "sesr_x4.crop.npz"))
+    e = sesrq.Engine(bundle_from_oracle(net), _dev())
+    x = rand_frame((4, 1, 540, 960), 4)
+    xt = torch.from_numpy(x).to(_dev())
+    q, y = e.forward(xt)
+    assert tuple(q.shape) == (4, 1, 2160, 3840)
+    want = CO.forward(net, x[:1], want_f=False)["q_out"]
+    _cmp("frame 0 vs C oracle", q[:1], want)
+    for i in range(1, 4):
+        qi, _ = e.forward(xt[i:i + 1].contiguous())
+        assert torch.equal(qi, q[i:i + 1])
+
+
+def test_config5_shape_nrdm6_then_sesr_x2_chain():
+    """BASELINE config 5 shape: an 8-conv NRDM net, its float output handed to SESR-x2 (float hand-off between
+    nets).  The reference has no integer path for either the 8-conv depth or the chain: parity
+    UNPINNED -- oracle chain vs HIP chain self-consistency."""
+    nr = O.synth_net("nrdm", 21, n_blocks=6)
+    sr = O.synth_net("sesr_x2", 22)
+    e1 = sesrq.Engine(bundle_from_oracle(nr), _dev())
+    e2 = sesrq.Engine(bundle_from_oracle(sr), _dev())
+    x = rand_frame((2, 3, 45, 83), 6)
+    _, y1 = e1.forward(torch.from_numpy(x).to(_dev()))
+    q2, y2 = e2.forward(y1)
+    w1 = O.forward(nr, x)
+    w2 = O.forward(sr, w1["y"])
+    _cmp("nrdm_6 float output", y1, w1["y"])
+    _cmp("chain int8 output", q2, w2["q_out"])
+    assert tuple(q2.shape) == (2, 3, 90, 166)
