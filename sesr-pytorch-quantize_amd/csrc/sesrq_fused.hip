@@ -28,7 +28,6 @@ namespace sesrq {
 
 constexpr int FW = 64;    // strip width (output pixels)
 constexpr int PA = 88;    // ring row pitch in pixels; column index c = u + 2
-constexpr int HT = 5;     // 16-pixel tiles per hidden row
 constexpr int DI = 8, D1 = 8, D2 = 4, D3 = 4, D4 = 8;   // ring depths (rows), powers of two
 constexpr int SUI = 23;   // input ring: 16-byte units per row per shifted copy (92 pixels)
 constexpr int INW = 89;   // input pixels per row: u = -2 .. 86

@@ -688,8 +688,7 @@ static void launch(K kern, ConvArgs a, hipStream_t st) {
         blocks_per_cu = it->second;
     }
     const int strips = (a.W + MTW - 1) / MTW, row_tiles = (a.H + MTH - 1) / MTH;
-    static const int frac_pct = getenv("SESRQ_GRID_PCT") ? atoi(getenv("SESRQ_GRID_PCT")) : 100;   // experiment knob
-    long long k = ((long long)blocks_per_cu * num_cu * frac_pct / 100) / ((long long)strips * a.N);
+    long long k = ((long long)blocks_per_cu * num_cu) / ((long long)strips * a.N);
     k = std::max(1LL, std::min<long long>(k, row_tiles));
     a.chunk_tiles = (int)((row_tiles + k - 1) / k);
     dim3 grid(strips, (row_tiles + a.chunk_tiles - 1) / a.chunk_tiles, a.N);
