@@ -226,6 +226,29 @@ def run_case(name: str, out_dir: str) -> None:
     y = sim_run(x_crop)
     harvest(x_crop, y, "crop", full=False)
 
+    # (2b) hardware stimulus text: run the reference's own dump scripts on a 40x72 crop (2x3 tiles of 32)
+    if name in ("sesr_x4", "nrdm_3"):
+        import runpy
+        x_st = x_full[:, :, 3:3 + 40, 200:200 + 72].contiguous()
+        shutil.rmtree("output_txt", ignore_errors=True)
+        y = sim_run(x_st)
+        harvest(x_st, y, "stim", full=False)
+        txt = {}
+
+        def grab(prefix):
+            for root, _, files in os.walk("output_txt"):
+                for f in sorted(files):
+                    rel = os.path.relpath(os.path.join(root, f), "output_txt")
+                    txt[prefix + rel] = np.frombuffer(open(os.path.join(root, f), "rb").read(), dtype=np.uint8)
+        runpy.run_path(os.path.join(REF, "output.py"), run_name="__main__")
+        grab("output/")
+        shutil.rmtree("output_txt/input", ignore_errors=True)
+        runpy.run_path(os.path.join(REF, "output_end2end.py"), run_name="__main__")
+        for f in sorted(os.listdir("output_txt/input")):
+            txt["end2end/input/" + f] = np.frombuffer(open(os.path.join("output_txt/input", f), "rb").read(), dtype=np.uint8)
+        np.savez_compressed(os.path.join(out_dir, f"{name}.stimtxt.npz"), **{k.replace("/", "|"): v for k, v in txt.items()})
+        print(f"[{name}.stimtxt] {len(txt)} text files, {sum(v.size for v in txt.values())} bytes", flush=True)
+
     def set_zero(vals):
         for k, v in vals.items():
             torch.save(int(v), f"output_pt/input/input.{k}.zero.pt")
