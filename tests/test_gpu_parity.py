@@ -17,7 +17,7 @@ from sesrq import _lib
 
 pytestmark = pytest.mark.gpu
 
-STAGE_FILES = [f for f in golden_files() if not f.endswith((".params.npz", "tables.npz"))]
+STAGE_FILES = [f for f in golden_files() if not f.endswith((".params.npz", "tables.npz", ".stimtxt.npz"))]
 ENGINES = [("dot4", _lib.ENGINE_DOT4), ("mfma", _lib.ENGINE_MFMA), ("fused", _lib.ENGINE_FUSED)]
 
 

@@ -10,7 +10,7 @@ import pytest
 from conftest import golden_files, load_fixture, fixture_input, GOLDEN
 from oracle import sesrq_oracle as O
 
-STAGE_FILES = [f for f in golden_files() if not f.endswith((".params.npz", "tables.npz"))]
+STAGE_FILES = [f for f in golden_files() if not f.endswith((".params.npz", "tables.npz", ".stimtxt.npz"))]
 
 
 def _sha(a):
