@@ -33,7 +33,10 @@ enum { SESRQ_F32 = 0, SESRQ_I8 = 1 };
 
 /* kernel families (sesrq_set_option(net, SESRQ_OPT_ENGINE, ...)) */
 enum { SESRQ_ENGINE_AUTO = 0, SESRQ_ENGINE_DOT4 = 1, SESRQ_ENGINE_MFMA = 2, SESRQ_ENGINE_FUSED = 3 };
-enum { SESRQ_OPT_ENGINE = 1, SESRQ_OPT_FORCE_GENERAL = 2, SESRQ_OPT_EXACT_DIV = 3 };
+enum { SESRQ_OPT_ENGINE = 1, SESRQ_OPT_FORCE_GENERAL = 2, SESRQ_OPT_EXACT_DIV = 3,
+       /* add the nearest-upsampled fp32 input frame to the fp32 output (the x2 "anchor" of the reference's eval
+        * loop, test.py:148-155: gfake + inps_x2); needs Cin == Cout and an fp32 input; int8 output unaffected */
+       SESRQ_OPT_ANCHOR_ADD = 4 };
 
 /* One collapsed convolution with its integer epilogue.
  *   w         : conv.weight.K.pt   (myQL/quan_func.py:71,78)  [oc][ic][k][k] int8

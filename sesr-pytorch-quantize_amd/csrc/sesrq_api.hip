@@ -290,6 +290,11 @@ int sesrq_set_option(sesrq_net *net, int option, int value) {
             return 0;
         case SESRQ_OPT_FORCE_GENERAL: net->force_general = value ? 1 : 0; return 0;
         case SESRQ_OPT_EXACT_DIV: net->force_exact_div = value ? 1 : 0; return 0;
+        case SESRQ_OPT_ANCHOR_ADD:
+            if (value && net->layers[0].ic * net->ps * net->ps != net->layers[net->L - 1].oc) {
+                set_error("sesrq_set_option: anchor add needs as many output as input channels"); return 1;
+            }
+            net->anchor_add = value ? 1 : 0; return 0;
     }
     set_error("sesrq_set_option: unknown option");
     return 1;
@@ -297,7 +302,7 @@ int sesrq_set_option(sesrq_net *net, int option, int value) {
 
 static bool use_fused(const sesrq_net *net, int in_dtype, const sesrq_taps *taps) {
     // opt-in only: correct, but slower than the per-layer MFMA kernels this round
-    return net->fused_ok && net->engine == SESRQ_ENGINE_FUSED && in_dtype == SESRQ_F32 && !taps;
+    return net->fused_ok && net->engine == SESRQ_ENGINE_FUSED && in_dtype == SESRQ_F32 && !taps && !net->anchor_add;
 }
 
 int sesrq_fast_division_proven(const sesrq_net *net) { return net ? net->fd.ok : 0; }
@@ -322,6 +327,7 @@ static int forward_impl(const sesrq_net *net, const void *in, int in_dtype, void
                         void *workspace, size_t workspace_bytes, void *stream, const sesrq_taps *taps, hipEvent_t *ev) {
     if (!net || !in || !workspace) { set_error("sesrq_forward: null argument"); return 1; }
     if (!out_q && !out_f) { set_error("sesrq_forward: both outputs are NULL"); return 1; }
+    if (net->anchor_add && in_dtype != SESRQ_F32) { set_error("sesrq_forward: anchor add needs the fp32 input frame"); return 1; }
     if (N < 1 || H < 1 || W < 1) { set_error("sesrq_forward: N, H, W must be positive"); return 1; }
     if ((size_t)N * H * W > (size_t)1 << 31) { set_error("sesrq_forward: frame batch too large (N*H*W > 2^31)"); return 1; }
     if (in_dtype != SESRQ_F32 && in_dtype != SESRQ_I8) { set_error("sesrq_forward: in_dtype must be SESRQ_F32 or SESRQ_I8"); return 1; }
@@ -386,6 +392,7 @@ static int forward_impl(const sesrq_net *net, const void *in, int in_dtype, void
         a.out = dst;
         a.rc_in = bufRC;
         a.out_q = out_q; a.out_f = (float *)out_f;
+        a.anchor = (net->anchor_add && in_dtype == SESRQ_F32) ? (const float *)in : nullptr;
         if (taps) {
             a.dbg_pe = (int *)taps->pe_out[k];
             a.dbg_add = (int *)taps->pe_add[k];

@@ -29,6 +29,7 @@ struct ConvArgs {
     void *rc_out;            // layer 0 only, when zero[1] != -128: separate rc tensor (else NULL)
     void *out_q;             // EPI_LAST: (N, C, H*r, W*r) int8 or NULL
     float *out_f;            // EPI_LAST: same shape fp32 or NULL
+    const float *anchor;     // EPI_LAST: fp32 input frame (N,C,H,W) added, nearest-upsampled, to out_f; or NULL
     const int *wpk;          // dot4: packed weights [tap][OCP][4] dwords (see pack_weights)
     const int4 *afrag;       // mfma: [4] add-constant words (row order) + A fragments [F][64] (pack_mfma_frags)
     const int4 *afrag2;      // mfma hybrid mode: the per-PE (general) fragment image; risky_pe selects the chain
@@ -108,6 +109,7 @@ struct sesrq_net {
     int engine = SESRQ_ENGINE_AUTO;
     int force_general = 0;
     int force_exact_div = 0;
+    int anchor_add = 0;
     int device = 0;
     bool rc_separate = false;   // zero[1] != -128 -> layer 0 writes its own rc tensor
     sesrq::FastDiv fd = {0, 0.f, 0.f, 0.f};

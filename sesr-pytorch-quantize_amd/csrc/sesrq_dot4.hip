@@ -188,7 +188,11 @@ __global__ __launch_bounds__(256) void conv_dot4_kernel(const ConvArgs a) {
                 const int c = o / r2, rem = o - c * r2, i = rem / r, j = rem - i * r;
                 const size_t off = (((size_t)n * cout + c) * Ho + (size_t)gy * r + i) * Wo + (size_t)gx * r + j;
                 if (a.out_q) reinterpret_cast<signed char *>(a.out_q)[off] = (signed char)(int)q;
-                if (a.out_f) a.out_f[off] = __fmul_rn(q - a.z_out, a.s_out);
+                if (a.out_f) {
+                    float yv = __fmul_rn(q - a.z_out, a.s_out);
+                    if (a.anchor) yv = __fadd_rn(yv, a.anchor[((size_t)n * cout + c) * HW + (size_t)gy * W + gx]);   // test.py:148-155
+                    a.out_f[off] = yv;
+                }
             }
         }
     }

@@ -78,6 +78,8 @@ __device__ __forceinline__ unsigned epi_preres(const int s[4], unsigned rcword, 
 struct LastStore {
     __amdgpu_buffer_rsrc_t rq, rf;
     int vo[4];            // element offset of slot i inside image n_img (out of range if invalid)
+    int va[4];            // anchor add: element offset of the slot's input pixel inside frame n_img (channel plane + column)
+    const float *anc;
     int r, row_elems;     // PixelShuffle factor, r * Wo
     __device__ __forceinline__ void init(const ConvArgs &a, int n_img, int g, int gx) {
         r = a.ps;
@@ -91,7 +93,9 @@ struct LastStore {
             const int o = 4 * g + i;
             const int c = o / r2, rem = o - c * r2, ii = rem / r, jj = rem - ii * r;
             vo[i] = (o < a.oc && gx < a.W) ? (c * Ho + ii) * Wo + gx * r + jj : (int)0x10000000;   // stays out of range times 4
+            va[i] = (o < a.oc && gx < a.W) ? c * a.H * a.W + gx : 0;
         }
+        anc = a.anchor ? a.anchor + (size_t)n_img * cout * a.H * a.W : nullptr;
     }
     template <bool BIASED>
     __device__ __forceinline__ void store(const int s[4], const ConvArgs &a, int gy, float zlo) const {
@@ -117,8 +121,11 @@ struct LastStore {
             const v2f q01 = c01 - mg, q23 = c23 - mg;      // exact: back to the integer-valued float
             const float q[4] = {q01[0], q01[1], q23[0], q23[1]};
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
-                __builtin_amdgcn_raw_buffer_store_b32(fbits(__fmul_rn(q[i] - a.z_out, a.s_out)), rf, vo[i] * 4, so * 4, 0);
+            for (int i = 0; i < 4; ++i) {
+                float yv = __fmul_rn(q[i] - a.z_out, a.s_out);
+                if (anc) yv = __fadd_rn(yv, anc[va[i] + gy * a.W]);          // + nearest-upsampled input (test.py:148-155)
+                __builtin_amdgcn_raw_buffer_store_b32(fbits(yv), rf, vo[i] * 4, so * 4, 0);
+            }
         }
     }
 };

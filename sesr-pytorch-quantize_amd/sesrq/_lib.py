@@ -16,7 +16,7 @@ MAX_LAYERS = 16
 MAX_CH = 16
 F32, I8 = 0, 1
 ENGINE_AUTO, ENGINE_DOT4, ENGINE_MFMA, ENGINE_FUSED = 0, 1, 2, 3
-OPT_ENGINE, OPT_FORCE_GENERAL, OPT_EXACT_DIV = 1, 2, 3
+OPT_ENGINE, OPT_FORCE_GENERAL, OPT_EXACT_DIV, OPT_ANCHOR_ADD = 1, 2, 3, 4
 
 
 class LayerDesc(C.Structure):

@@ -17,7 +17,7 @@ class Engine:
     the workspace for a given (N, H, W) exists."""
 
     def __init__(self, bundle: Bundle, device: Optional[torch.device] = None, engine: int = _lib.ENGINE_AUTO,
-                 force_general: bool = False, exact_division: bool = False):
+                 force_general: bool = False, exact_division: bool = False, anchor_add: bool = False):
         if not torch.cuda.is_available():
             raise RuntimeError("sesrq.Engine needs a HIP device (torch.cuda.is_available() is False); "
                                "there is no CPU fallback in this package")
@@ -47,6 +47,8 @@ class Engine:
             _lib.check(_lib.lib().sesrq_set_option(self._h, _lib.OPT_ENGINE, engine), ValueError)
         if force_general:
             _lib.check(_lib.lib().sesrq_set_option(self._h, _lib.OPT_FORCE_GENERAL, 1), ValueError)
+        if anchor_add:
+            _lib.check(_lib.lib().sesrq_set_option(self._h, _lib.OPT_ANCHOR_ADD, 1), ValueError)
         if exact_division:
             _lib.check(_lib.lib().sesrq_set_option(self._h, _lib.OPT_EXACT_DIV, 1), ValueError)
         self._ws: Dict[tuple, torch.Tensor] = {}

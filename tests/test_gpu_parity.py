@@ -311,3 +311,18 @@ def test_config5_shape_nrdm6_then_sesr_x2_chain():
     _cmp("nrdm_6 float output", y1, w1["y"])
     _cmp("chain int8 output", q2, w2["q_out"])
     assert tuple(q2.shape) == (2, 3, 90, 166)
+
+
+@pytest.mark.parametrize("eng", ENGINES[:2], ids=[e[0] for e in ENGINES[:2]])
+def test_x2_anchor_add(eng):
+    """SURVEY 8f-4: the x2 eval loop adds the nearest-upsampled input to the float output (test.py:148-155);
+    fused into the last epilogue as an option.  One fp32 add per output value -> bit-exact vs numpy."""
+    net = O.synth_net("sesr_x2", 3)
+    e = sesrq.Engine(bundle_from_oracle(net), _dev(), engine=eng[1], anchor_add=True)
+    x = rand_frame((2, 3, 37, 70), 12)
+    q, y = e.forward(torch.from_numpy(x).to(_dev()))
+    want = O.forward(net, x)
+    _cmp("int8 output unaffected", q, want["q_out"])
+    _cmp("y + upsampled input", y, want["y"] + np.repeat(np.repeat(x, 2, axis=2), 2, axis=3))
+    with pytest.raises(RuntimeError, match="anchor"):       # the anchor is the fp32 frame: an int8 input cannot provide it
+        e.forward(torch.from_numpy(O.quantize_input(x, net.scale[0], net.zero[0])).to(_dev()))
