@@ -91,6 +91,8 @@ class Engine:
             raise ValueError("Expect input tensor dimension: 4, but get %d" % x.dim())
         if x.device != self.device:
             raise ValueError(f"input is on {x.device}, engine on {self.device}")
+        if x.shape[0] < 1 or x.shape[2] < 1 or x.shape[3] < 1:
+            raise ValueError("empty frame: N, H and W must be positive")
         if x.shape[1] != self.bundle.in_channels:
             raise ValueError(f"expected {self.bundle.in_channels} input channels, got {x.shape[1]}")
         if x.dtype == torch.float32:

@@ -326,3 +326,40 @@ def test_x2_anchor_add(eng):
     _cmp("y + upsampled input", y, want["y"] + np.repeat(np.repeat(x, 2, axis=2), 2, axis=3))
     with pytest.raises(RuntimeError, match="anchor"):       # the anchor is the fp32 frame: an int8 input cannot provide it
         e.forward(torch.from_numpy(O.quantize_input(x, net.scale[0], net.zero[0])).to(_dev()))
+
+
+def test_randomised_shapes_against_c_oracle():
+    """Stress the tile / chunk / strip boundaries of the persistent kernels: random frame sizes (around multiples of
+    16 rows and 64 columns, tiny and tall), batches, all three topologies, merged / hybrid / general kernels."""
+    from oracle import c_oracle as CO
+    rng = np.random.default_rng(2024)
+    heights = [15, 16, 17, 31, 32, 33, 47, 48, 49, 63, 64, 65, 95, 97, 129, 255, 257, 300]
+    widths = [1, 2, 15, 16, 17, 63, 64, 65, 127, 128, 129, 191, 193, 250]
+    kinds = ["sesr_x4", "sesr_x2", "nrdm"]
+    for trial in range(24):
+        kind = kinds[trial % 3]
+        hard = (trial // 3) % 2 == 1
+        net = O.synth_net(kind, 100 + trial, hard=hard)
+        if trial % 4 == 3:                      # force exactly one risky PE in a random layer -> hybrid kernel
+            k = int(rng.integers(0, 5))
+            w = (net.layers[k].wq.astype(np.int32) // 2).astype(np.int8)
+            w[int(rng.integers(w.shape[0])), int(rng.integers(min(4, w.shape[1])))::4] = 127
+            net.layers[k].wq = w
+        e = sesrq.Engine(bundle_from_oracle(net), _dev())
+        H, W, N = int(rng.choice(heights)), int(rng.choice(widths)), int(rng.choice([1, 1, 2, 3]))
+        x = rng.random((N, net.layers[0].wq.shape[1], H, W), dtype=np.float32)
+        want = CO.forward(net, x)
+        q, y = e.forward(torch.from_numpy(x).to(_dev()))
+        _cmp(f"trial {trial} {net.name} {N}x{H}x{W} {e.layer_engines()} q", q, want["q_out"])
+        _cmp(f"trial {trial} y", y, want["y"])
+
+
+def test_empty_and_degenerate_inputs():
+    net = O.synth_net("nrdm", 1)
+    e = sesrq.Engine(bundle_from_oracle(net), _dev())
+    for shape in [(0, 3, 8, 8), (1, 3, 0, 8), (1, 3, 8, 0)]:
+        with pytest.raises(ValueError, match="positive"):
+            e.forward(torch.zeros(shape, device=_dev()))
+    # a constant frame is fine in the integer path (only the calibration observer rejects "all equal")
+    q, _ = e.forward(torch.full((1, 3, 5, 7), 0.25, device=_dev()))
+    _cmp("constant frame", q, O.forward(net, np.full((1, 3, 5, 7), 0.25, np.float32))["q_out"])
