@@ -90,10 +90,13 @@ static void pack_mfma_frags(const sesrq_layer_desc &d, int kind, bool general, b
         case MFMA_H3: F = general ? 4 : 3; break;
         case MFMA_H5: F = general ? 8 : 10; break;
         case MFMA_F5: F = general ? 12 : 3; break;
+        case MFMA_H5P: F = 7; break;
     }
     out.assign((size_t)16 + (size_t)F * 64 * 4, 0);
-    auto ocmap = [&](int m) { return last ? m : (m >> 2) + 4 * (m & 3); };
-    for (int m = 0; m < 16; ++m) out[m] = ocmap(m) < d.oc ? d.add_const[ocmap(m)] : 0;
+    // MFMA_H5P (last layer, OC <= 4): accumulator row m = (PE m/4, output channel m%4); a row only carries
+    // the weights of its PE's channels, so one chain over the full K yields the four per-PE sums
+    auto ocmap = [&](int m) { return kind == MFMA_H5P ? (m & 3) : (last ? m : (m >> 2) + 4 * (m & 3)); };
+    for (int m = 0; m < 16; ++m) out[m] = (ocmap(m) < d.oc && !(kind == MFMA_H5P && m > 3)) ? d.add_const[ocmap(m)] : 0;
     auto chmap16 = [](int b) { return (b >> 2) + 4 * (b & 3); };
     signed char *bytes = reinterpret_cast<signed char *>(out.data() + 16);
     for (int f = 0; f < F; ++f)
@@ -111,6 +114,12 @@ static void pack_mfma_frags(const sesrq_layer_desc &d, int kind, bool general, b
                     else if (g == 0) { ky = 4; kx = i; }
                     else if (g == 1) { ky = i; kx = 4; }
                     else if (g == 2 && i == 0) { ky = 4; kx = 4; }
+                } else if (kind == MFMA_H5P) {
+                    ch = chmap16(b);
+                    if (f < 5) { ky = f; kx = g; }
+                    else if (f == 5) { ky = g; kx = 4; }
+                    else if (g == 0) { ky = 4; kx = 4; }
+                    if ((b >> 2) != (m >> 2)) ky = -1;              // byte group i = PE of the channel
                 } else if (kind == MFMA_F5) {
                     const int npe = general ? 4 : 1, fi = f / npe, p = f % npe;
                     static const int tky[3][4] = {{0, 1, 2, 3}, {4, 0, 1, 2}, {3, 4, -1, -1}};
@@ -234,6 +243,16 @@ int sesrq_create(const sesrq_net_desc *d, sesrq_net **out) {
                     return 1;
                 }
             }
+            if (k == L - 1 && lp.mfma_kind == MFMA_H5 && l.oc <= 4) {
+                std::vector<int> fr;
+                pack_mfma_frags(l, MFMA_H5P, true, true, fr);
+                if (hipMalloc((void **)&lp.d_afrag_pesplit, fr.size() * sizeof(int)) != hipSuccess ||
+                    hipMemcpy(lp.d_afrag_pesplit, fr.data(), fr.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess) {
+                    set_error("sesrq_create: device upload failed");
+                    sesrq_destroy(net);
+                    return 1;
+                }
+            }
         }
         ConvArgs &a = lp.base;
         memset(&a, 0, sizeof(a));
@@ -255,6 +274,7 @@ int sesrq_create(const sesrq_net_desc *d, sesrq_net **out) {
         static const char *kn[] = {"", "mfma-h3", "mfma-h5", "mfma-f5"};
         const bool hyb = lp.general && __builtin_popcount(lp.risky_mask) == 1 && d->pe_acc_bits == 18 && d->pe_add_bits == 20;
         lp.engine_mfma = lp.mfma_kind == MFMA_NONE ? lp.engine_dot4 : std::string(kn[lp.mfma_kind]) + (hyb ? "-hybrid" : (lp.general ? "-general" : "-merged"));
+        if (lp.d_afrag_pesplit) lp.engine_mfma = std::string("mfma-h5p-") + (lp.general ? "general" : "merged");
         lp.engine = lp.engine_mfma;
     }
     net->fd = prove_fastdiv(d->scale_in, d->zero[0]);
@@ -275,6 +295,7 @@ void sesrq_destroy(sesrq_net *net) {
         if (lp.d_wpk_merged) (void)hipFree(lp.d_wpk_merged);
         if (lp.d_afrag_general) (void)hipFree(lp.d_afrag_general);
         if (lp.d_afrag_merged) (void)hipFree(lp.d_afrag_merged);
+        if (lp.d_afrag_pesplit) (void)hipFree(lp.d_afrag_pesplit);
     }
     delete net;
 }
@@ -408,6 +429,7 @@ static int forward_impl(const sesrq_net *net, const void *in, int in_dtype, void
             // exactly one PE can saturate (and nothing forces the full per-PE path): merged chain + that PE's chain
             const bool one_pe = lp.general && !net->force_general && !dbg && __builtin_popcount(lp.risky_mask) == 1;
             if (one_pe) { a.afrag = lp.d_afrag_merged; a.afrag2 = lp.d_afrag_general; a.risky_pe = __builtin_ctz(lp.risky_mask); }
+            if (lp.d_afrag_pesplit) a.afrag = lp.d_afrag_pesplit;
             if (launch_mfma(lp, a, src, epi, eff.general, st, one_pe)) return 1;
         } else if (launch_dot4(eff, a, src, epi, st)) return 1;
         if (ev && hipEventRecord(ev[2 * k + 1], st) != hipSuccess) { set_error("hipEventRecord failed"); return 1; }

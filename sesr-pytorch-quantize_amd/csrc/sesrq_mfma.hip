@@ -81,24 +81,40 @@ struct LastStore {
     int va[4];            // anchor add: element offset of the slot's input pixel inside frame n_img (channel plane + column)
     const float *anc;
     int r, row_elems;     // PixelShuffle factor, r * Wo
-    __device__ __forceinline__ void init(const ConvArgs &a, int n_img, int g, int gx) {
-        r = a.ps;
-        const int r2 = r * r, Ho = a.H * r, Wo = a.W * r, cout = a.oc / r2;
+    // lane_row: the lane's output row relative to the row passed to store() (pe-split kernel: lane group = row)
+    template <int R>
+    __device__ __forceinline__ void init_r(const ConvArgs &a, int n_img, int g, int gx, int lane_row) {
+        r = R;
+        constexpr int r2 = R * R;
+        const int Ho = a.H * R, Wo = a.W * R, cout = a.oc / r2;
         const size_t img = (size_t)cout * Ho * Wo;
         rq = __builtin_amdgcn_make_buffer_rsrc((char *)a.out_q + (size_t)n_img * img, 0, a.out_q ? (int)img : 0, 0x00020000);
         rf = __builtin_amdgcn_make_buffer_rsrc((char *)a.out_f + (size_t)n_img * img * 4, 0, a.out_f ? (int)(img * 4) : 0, 0x00020000);
-        row_elems = r * Wo;
+        row_elems = R * Wo;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int o = 4 * g + i;
-            const int c = o / r2, rem = o - c * r2, ii = rem / r, jj = rem - ii * r;
-            vo[i] = (o < a.oc && gx < a.W) ? (c * Ho + ii) * Wo + gx * r + jj : (int)0x10000000;   // stays out of range times 4
-            va[i] = (o < a.oc && gx < a.W) ? c * a.H * a.W + gx : 0;
+            const int c = o / r2, rem = o - c * r2, ii = rem / R, jj = rem - ii * R;
+            vo[i] = (o < a.oc && gx < a.W) ? (c * Ho + ii + lane_row * R) * Wo + gx * R + jj : (int)0x10000000;   // stays out of range times 4
+            va[i] = (o < a.oc && gx < a.W) ? c * a.H * a.W + gx + lane_row * a.W : 0;
         }
         anc = a.anchor ? a.anchor + (size_t)n_img * cout * a.H * a.W : nullptr;
     }
+    // the shuffle factor is a constant in each branch: the slot decode costs shifts, not integer divisions
+    __device__ __forceinline__ void init(const ConvArgs &a, int n_img, int g, int gx, int lane_row = 0) {
+        switch (a.ps) {
+            case 1: init_r<1>(a, n_img, g, gx, lane_row); break;
+            case 2: init_r<2>(a, n_img, g, gx, lane_row); break;
+            case 3: init_r<3>(a, n_img, g, gx, lane_row); break;
+            default: init_r<4>(a, n_img, g, gx, lane_row); break;
+        }
+    }
+    // gy: wave-uniform row; row_ok: false drops this lane's stores (lanes whose own row gy + lane_row is below the frame)
     template <bool BIASED>
-    __device__ __forceinline__ void store(const int s[4], const ConvArgs &a, int gy, float zlo) const {
+    __device__ __forceinline__ void store(const int s[4], const ConvArgs &a, int gy, float zlo, bool row_ok = true) const {
+        int vo[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) vo[i] = row_ok ? this->vo[i] : (int)0x10000000;
         v2f v01, v23;
         requant4<BIASED>(s, a.Mf, a.sh, a.z_out, v01, v23);
         const v2f mg = {MAGIC, MAGIC};
@@ -123,7 +139,7 @@ struct LastStore {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 float yv = __fmul_rn(q[i] - a.z_out, a.s_out);
-                if (anc) yv = __fadd_rn(yv, anc[va[i] + gy * a.W]);          // + nearest-upsampled input (test.py:148-155)
+                if (anc && row_ok) yv = __fadd_rn(yv, anc[va[i] + gy * a.W]);   // + nearest-upsampled input (test.py:148-155)
                 __builtin_amdgcn_raw_buffer_store_b32(fbits(yv), rf, vo[i] * 4, so * 4, 0);
             }
         }
@@ -504,6 +520,88 @@ __global__ __launch_bounds__(256) void mfma_h5_kernel(const ConvArgs a) {
 #undef SESRQ_COMPUTE
 }
 
+// ------------------------------------------------------------------ last layer 5x5, 16 -> OC <= 4 (x2 nets), "pe-split"
+// The 16 accumulator rows are (PE p, output channel o) = row 4p + o (pack_mfma_frags, MFMA_H5P): ONE chain
+// over the full K (7 K-chunks, the B operands of the merged kernel) leaves PE g's four sums in lane group g.
+// After the 18-bit clamp, a transpose-reduce over four pixel rows (12 permlane swaps + 12 adds) puts the
+// complete adder sum of row r in lane group r: every lane then requantises and stores 4 real outputs.
+//   K-chunk f < 5: lane group g = tap (ky f, kx g)     f = 5: (ky g, kx 4)     f = 6: g0 = (4, 4)
+template <int MODE>
+__global__ __launch_bounds__(256) void mfma_h5p_kernel(const ConvArgs a) {
+    constexpr int SW = MTW + 8;
+    constexpr int SH = MTH + 4;
+    __shared__ int4 buf0[SH * SW], buf1[SH * SW];
+    const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, n = l & 15, g = l >> 4;
+    const int x0 = blockIdx.x * MTW, n_img = blockIdx.z;
+    const int4 *fr = a.afrag;
+    constexpr bool BIASED = MODE != GEN_ANY;
+    int4 ac = fr[0];
+    if constexpr (BIASED) { ac.x += MAGIC_I; ac.y += MAGIC_I; ac.z += MAGIC_I; ac.w += MAGIC_I; }
+    const float zlo = a.relu ? fmaxf(a.z_out, -128.f) : -128.f;
+    const int gx = x0 + 16 * w + n;
+    v4i A[7];
+#pragma unroll
+    for (int f = 0; f < 7; ++f) A[f] = ld_frag(fr + 4 + f * 64 + l);
+    LastStore ls;
+    ls.init(a, n_img, 0, gx, g);
+    auto compute = [&](const int4 *tile, int y0) __attribute__((always_inline)) {
+        const int col = 16 * w + n + g, colc = 16 * w + n + 4;
+        const v4i zero = {0, 0, 0, 0};
+        // merged: nothing can clamp -> the add constant rides in PE 0's accumulator rows
+        const v4i acc0 = (MODE == MERGED && g == 0) ? (v4i){ac.x, ac.y, ac.z, ac.w} : zero;
+        v4i B[5];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) B[r] = ld_frag(tile + r * SW + col);
+#pragma unroll
+        for (int y4 = 0; y4 < MTH; y4 += 4) {
+            unsigned s[4][4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int y = y4 + r;
+                B[(y + 4) % 5] = ld_frag(tile + (y + 4) * SW + col);
+                const v4i C5 = ld_frag(tile + (y + g) * SW + colc);
+                const v4i C6 = ld_frag(tile + (y + 4) * SW + colc);
+                v4i acc = acc0;
+#pragma unroll
+                for (int ky = 0; ky < 5; ++ky) acc = mfma(A[ky], B[(y + ky) % 5], acc);
+                acc = mfma(A[5], C5, acc);
+                acc = mfma(A[6], C6, acc);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    if constexpr (MODE == MERGED) s[r][i] = (unsigned)acc[i];
+                    else if constexpr (MODE == GEN_ANY) s[r][i] = (unsigned)clampi3(acc[i], a.acc_lo, a.acc_hi);
+                    else s[r][i] = (unsigned)clampi3(acc[i], -131072, 131071);
+                }
+            }
+            int t[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                // lane halves trade rows {0,1} against {2,3}: u0 = row 0 | row 2, u1 = row 1 | row 3 (PE g + PE g^2)
+                v2u x = __builtin_amdgcn_permlane32_swap(s[0][i], s[2][i], false, false);
+                const unsigned u0 = x[0] + x[1];
+                x = __builtin_amdgcn_permlane32_swap(s[1][i], s[3][i], false, false);
+                const unsigned u1 = x[0] + x[1];
+                // odd lane groups trade with even ones: lane group r ends up with row r, all four PEs
+                x = __builtin_amdgcn_permlane16_swap(u0, u1, false, false);
+                t[i] = (int)(x[0] + x[1]);
+            }
+            int sf[4];
+            const int acv[4] = {ac.x, ac.y, ac.z, ac.w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                if constexpr (MODE == MERGED) sf[i] = t[i];
+                else if constexpr (MODE == GEN_ANY) sf[i] = clampi3(t[i], a.add_lo, a.add_hi) + acv[i];
+                else sf[i] = clampi3(t[i], -524288, 524287) + acv[i];
+            }
+            if (y0 + y4 < a.H) ls.store<BIASED>(sf, a, y0 + y4, zlo, y0 + y4 + g < a.H);
+        }
+    };
+#define SESRQ_COMPUTE(B) compute(B, y0);
+    using Stage = StageNHWC16<SH, SW, 2>;
+    SESRQ_TILE_WALK(Stage, buf0, buf1, SESRQ_COMPUTE)
+#undef SESRQ_COMPUTE
+}
+
 // ------------------------------------------------------------------ first layer 5x5, IC <= 4
 // The frame is quantised while it is staged (q0 = clamp8(rint(x/s0 + z0)), quan_func.py:225);
 // a pixel is one dword (byte c = channel c).  A lane's 16 bytes = 4 horizontally adjacent pixels
@@ -726,6 +824,12 @@ int launch_mfma(const LayerPlan &lp, const ConvArgs &a_in, int src, int epi, boo
             else { set_error("mfma: 3x3 last layer not supported"); return 1; }
             break;
         case MFMA_H5:
+            if (epi == EPI_LAST && lp.d_afrag_pesplit && a.afrag == lp.d_afrag_pesplit) {
+                if (mode == MERGED) launch(mfma_h5p_kernel<MERGED>, a, st);
+                else if (mode == GEN_ANY) launch(mfma_h5p_kernel<GEN_ANY>, a, st);
+                else launch(mfma_h5p_kernel<GEN_STD>, a, st);
+                break;
+            }
             if (epi == EPI_MID) SESRQ_BY_MODE(mfma_h5_kernel, EPI_MID);
             else if (epi == EPI_PRERES) SESRQ_BY_MODE(mfma_h5_kernel, EPI_PRERES);
             else SESRQ_BY_MODE(mfma_h5_kernel, EPI_LAST);

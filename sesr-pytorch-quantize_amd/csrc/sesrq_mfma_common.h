@@ -92,5 +92,4 @@ __device__ __forceinline__ unsigned round_pack(v2f v01, v2f v23, float lo, float
     return pack_lo_bytes(fbits(c01[0]), fbits(c01[1]), fbits(c23[0]), fbits(c23[1]));
 }
 
-
 }  // namespace sesrq

@@ -219,19 +219,20 @@ def test_fast_division_is_proven_and_equals_exact_division():
         assert sesrq.Engine(bundle_from_oracle(gnet), _dev()).fast_division_proven(), tag
 
 
-@pytest.mark.parametrize("layer", [0, 1, 3, 4])
-def test_hybrid_single_risky_pe(layer):
+@pytest.mark.parametrize("layer,arch", [(0, "sesr_x2"), (1, "sesr_x2"), (3, "sesr_x2"), (4, "sesr_x4"), (4, "sesr_x2"), (4, "nrdm")])
+def test_hybrid_single_risky_pe(layer, arch):
     """Exactly one PE of a layer can saturate -> merged chain + that PE's chain ('hybrid' kernels).  The
     weights of one (oc, PE) pair are blown up so that the 18-bit clamp really fires."""
-    net = O.synth_net("sesr_x2", 7)
+    net = O.synth_net(arch, 7)
     w = (net.layers[layer].wq.astype(np.int32) // 2).astype(np.int8)     # keep the other three PEs provably safe
     pe = 2 if layer == 0 else 1
     w[5 % w.shape[0], pe::4, :, :] = 127
     w[7 % w.shape[0], pe::4, :, :] = -128
     net.layers[layer].wq = w
     e = sesrq.Engine(bundle_from_oracle(net), _dev(), engine=_lib.ENGINE_MFMA)
-    assert "hybrid" in e.layer_engines()[layer], e.layer_engines()
-    x = rand_frame((2, 3, 41, 77), 21)
+    # a last layer with OC <= 4 runs the pe-split kernel (all four PE sums come out of one chain anyway)
+    assert ("h5p-general" if (layer == 4 and arch == "nrdm") else "hybrid") in e.layer_engines()[layer], e.layer_engines()
+    x = rand_frame((2, net.layers[0].wq.shape[1], 41, 77), 21)
     x[0, :, :20] = 1.0                       # bright region: large positive PE sums
     want = O.forward(net, x, keep=False)
     q, y = e.forward(torch.from_numpy(x).to(_dev()))
