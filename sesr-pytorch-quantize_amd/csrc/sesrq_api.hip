@@ -89,7 +89,8 @@ static void pack_mfma_frags(const sesrq_layer_desc &d, int kind, bool general, b
     switch (kind) {
         case MFMA_H3: F = general ? 4 : 3; break;
         case MFMA_H5: F = general ? 8 : 10; break;
-        case MFMA_F5: F = general ? 12 : 3; break;
+        case MFMA_F5: F = general ? 8 : 2; break;
+        case MFMA_F5L: F = general ? 12 : 3; break;
         case MFMA_H5P: F = 7; break;
     }
     out.assign((size_t)16 + (size_t)F * 64 * 4, 0);
@@ -121,6 +122,22 @@ static void pack_mfma_frags(const sesrq_layer_desc &d, int kind, bool general, b
                     else if (g == 0) { ky = 4; kx = 4; }
                     if ((b >> 2) != (m >> 2)) ky = -1;              // byte group i = PE of the channel
                 } else if (kind == MFMA_F5) {
+                    // K-chunk 0: lane group g = kernel row g, dwords = kx 0..3.  K-chunk 1: the 9 remaining taps (row 4 and
+                    // column 4) are covered by FOUR translates of ONE 4-pixel pattern {(0,0),(1,0),(2,0),(2,2)}, so a single
+                    // pair of ds_read2_b32 (same immediate offsets in every lane) fetches every lane group's operand.
+                    const int npe = general ? 4 : 1, fi = f / npe, p = f % npe;
+                    static const int tr[4][2] = {{0, 4}, {2, 0}, {2, 1}, {2, 4}};       // (row, column) translation of lane group g
+                    static const int pt[4][2] = {{0, 0}, {1, 0}, {2, 0}, {2, 2}};       // the pattern, dword i
+                    ch = j;
+                    if (fi == 0) { ky = g; kx = i; }
+                    else {
+                        ky = tr[g][0] + pt[i][0]; kx = tr[g][1] + pt[i][1];
+                        const bool in_l = (ky == 4 && kx <= 4) || (kx == 4 && ky <= 4);   // taps not in K-chunk 0
+                        const bool dup = (g == 3 && i == 0);                              // (2,4) belongs to lane group 0
+                        if (!in_l || dup) ky = -1;
+                    }
+                    if (general && ch != p) ky = -1;
+                } else if (kind == MFMA_F5L) {
                     const int npe = general ? 4 : 1, fi = f / npe, p = f % npe;
                     static const int tky[3][4] = {{0, 1, 2, 3}, {4, 0, 1, 2}, {3, 4, -1, -1}};
                     static const int tsg[3][4] = {{0, 0, 0, 0}, {0, 1, 1, 1}, {1, 1, 0, 0}};
@@ -243,6 +260,19 @@ int sesrq_create(const sesrq_net_desc *d, sesrq_net **out) {
                     return 1;
                 }
             }
+            if (lp.mfma_kind == MFMA_F5) {
+                for (int gen = 0; gen < 2; ++gen) {
+                    std::vector<int> fr;
+                    pack_mfma_frags(l, MFMA_F5L, gen == 1, false, fr);
+                    int4 **dst = gen ? &lp.d_afrag_f5l_general : &lp.d_afrag_f5l_merged;
+                    if (hipMalloc((void **)dst, fr.size() * sizeof(int)) != hipSuccess ||
+                        hipMemcpy(*dst, fr.data(), fr.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess) {
+                        set_error("sesrq_create: device upload failed");
+                        sesrq_destroy(net);
+                        return 1;
+                    }
+                }
+            }
             if (k == L - 1 && lp.mfma_kind == MFMA_H5 && l.oc <= 4) {
                 std::vector<int> fr;
                 pack_mfma_frags(l, MFMA_H5P, true, true, fr);
@@ -296,6 +326,8 @@ void sesrq_destroy(sesrq_net *net) {
         if (lp.d_afrag_general) (void)hipFree(lp.d_afrag_general);
         if (lp.d_afrag_merged) (void)hipFree(lp.d_afrag_merged);
         if (lp.d_afrag_pesplit) (void)hipFree(lp.d_afrag_pesplit);
+        if (lp.d_afrag_f5l_general) (void)hipFree(lp.d_afrag_f5l_general);
+        if (lp.d_afrag_f5l_merged) (void)hipFree(lp.d_afrag_f5l_merged);
     }
     delete net;
 }
@@ -380,6 +412,7 @@ static int forward_impl(const sesrq_net *net, const void *in, int in_dtype, void
             const LayerPlan &lp = net->layers[k];
             const bool g = (k == 0) ? gen[0] : (k == 4 ? gen[4] : genh);
             f.l[k].afrag = g ? lp.d_afrag_general : lp.d_afrag_merged;
+            if (k == 0) f.l[k].afrag = g ? lp.d_afrag_f5l_general : lp.d_afrag_f5l_merged;
             f.l[k].Mf = lp.base.Mf; f.l[k].sh = lp.base.sh; f.l[k].z_next = lp.base.z_next;
             f.l[k].pad_next = (k < 4) ? net->layers[k + 1].base.pad_word : 0;
         }

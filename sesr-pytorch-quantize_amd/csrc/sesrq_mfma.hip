@@ -690,26 +690,24 @@ __global__ __launch_bounds__(256) void mfma_f5_kernel(const ConvArgs a) {
     int4 ac = fr[g];
     if constexpr (BIASED) { ac.x += MAGIC_I; ac.y += MAGIC_I; ac.z += MAGIC_I; ac.w += MAGIC_I; }
     constexpr int NPE = GENERAL ? 4 : 1;
-    v4i A[3][NPE];
+    v4i A[2][NPE];
 #pragma unroll
-    for (int f = 0; f < 3; ++f)
+    for (int f = 0; f < 2; ++f)
 #pragma unroll
         for (int p = 0; p < NPE; ++p) A[f][p] = ld_frag(fr + 4 + (f * NPE + p) * 64 + l);
-    v4i AR[3] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+    v4i AR[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
     if constexpr (MODE == HYB) {
 #pragma unroll
-        for (int f = 0; f < 3; ++f) AR[f] = ld_frag(a.afrag2 + 4 + (f * 4 + a.risky_pe) * 64 + l);
+        for (int f = 0; f < 2; ++f) AR[f] = ld_frag(a.afrag2 + 4 + (f * 4 + a.risky_pe) * 64 + l);
     }
-    // lane group -> (kernel row, 4-pixel segment) per K-chunk; must match pack_mfma_frags (MFMA_F5)
-    //   f0: (g,0)      f1: (4,0) (0,1) (1,1) (2,1)      f2: (3,1) (4,1) - -
-    int addr[3];
+    // lane group -> first pixel of its operand per K-chunk; must match pack_mfma_frags (MFMA_F5)
+    //   chunk 0: row g, 4 horizontally adjacent pixels          (dwords +0 +1 +2 +3)
+    //   chunk 1: pattern {(0,0),(1,0),(2,0),(2,2)} translated by (0,4) (2,0) (2,1) (2,4)   (dwords +0 +P +2P +2P+2)
+    int addr[2];
     {
-        const int rowofs[3] = {g, g == 0 ? 4 : g - 1, g == 0 ? 3 : (g == 1 ? 4 : 0)};
-        const int seg[3] = {0, g == 0 ? 0 : 1, g < 2 ? 1 : 0};
-#pragma unroll
-        for (int f = 0; f < 3; ++f) {
-            addr[f] = rowofs[f] * PITCH + 16 * w + n + 4 * seg[f];    // first of the 4 pixels, in pixels
-        }
+        const int tr_r = g == 0 ? 0 : 2, tr_c = g == 0 ? 4 : (g == 1 ? 0 : (g == 2 ? 1 : 4));
+        addr[0] = g * PITCH + 16 * w + n;
+        addr[1] = tr_r * PITCH + 16 * w + n + tr_c;
     }
     const float zlo = a.relu ? fmaxf(a.z_next, -128.f) : -128.f;
     const int gx = x0 + 16 * w + n;
@@ -722,8 +720,8 @@ __global__ __launch_bounds__(256) void mfma_f5_kernel(const ConvArgs a) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int y = y4 + r;
-                const int *p0 = cpw + addr[0] + y * PITCH, *p1 = cpw + addr[1] + y * PITCH, *p2 = cpw + addr[2] + y * PITCH;
-                const v4i B0 = {p0[0], p0[1], p0[2], p0[3]}, B1 = {p1[0], p1[1], p1[2], p1[3]}, B2 = {p2[0], p2[1], p2[2], p2[3]};
+                const int *p0 = cpw + addr[0] + y * PITCH, *p1 = cpw + addr[1] + y * PITCH;
+                const v4i B0 = {p0[0], p0[1], p0[2], p0[3]}, B1 = {p1[0], p1[PITCH], p1[2 * PITCH], p1[2 * PITCH + 2]};
                 v4i acc[GENERAL ? 4 : (MODE == HYB ? 2 : 1)];
                 const v4i zero = {0, 0, 0, 0};
                 if constexpr (GENERAL) {
@@ -731,17 +729,14 @@ __global__ __launch_bounds__(256) void mfma_f5_kernel(const ConvArgs a) {
                     for (int p = 0; p < 4; ++p) {
                         acc[p] = mfma(A[0][p], B0, zero);
                         acc[p] = mfma(A[1][p], B1, acc[p]);
-                        acc[p] = mfma(A[2][p], B2, acc[p]);
                     }
                 } else {
                     const v4i acc0 = (MODE == HYB) ? zero : (v4i){ac.x, ac.y, ac.z, ac.w};
                     acc[0] = mfma(A[0][0], B0, acc0);
                     acc[0] = mfma(A[1][0], B1, acc[0]);
-                    acc[0] = mfma(A[2][0], B2, acc[0]);
                     if constexpr (MODE == HYB) {       // same B operands, A masked to the risky PE's channel
                         acc[1] = mfma(AR[0], B0, zero);
                         acc[1] = mfma(AR[1], B1, acc[1]);
-                        acc[1] = mfma(AR[2], B2, acc[1]);
                     }
                 }
                 finish_sums<MODE>(s4[r], acc, ac, a);
