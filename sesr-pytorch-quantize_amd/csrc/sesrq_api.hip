@@ -88,7 +88,8 @@ static void pack_mfma_frags(const sesrq_layer_desc &d, int kind, bool general, b
     int F = 0;
     switch (kind) {
         case MFMA_H3: F = general ? 4 : 3; break;
-        case MFMA_H5: F = general ? 8 : 10; break;
+        case MFMA_H5: F = general ? 8 : 7; break;
+        case MFMA_H5L: F = general ? 8 : 10; break;
         case MFMA_F5: F = general ? 8 : 2; break;
         case MFMA_F5L: F = general ? 12 : 3; break;
         case MFMA_H5P: F = 7; break;
@@ -107,8 +108,29 @@ static void pack_mfma_frags(const sesrq_layer_desc &d, int kind, bool general, b
                 int ky = -1, kx = -1, ch = -1;
                 if (kind == MFMA_H3 && !general) { ky = f; kx = g; ch = chmap16(b); if (g > 2) ky = -1; }
                 else if (kind == MFMA_H3) { const int p = f; ky = g; kx = i; ch = p + 4 * j; if (g > 2 || i > 2) ky = -1; }
-                else if (kind == MFMA_H5 && !general) { ky = f >> 1; kx = 4 * (f & 1) + g; ch = chmap16(b); if (kx > 4) ky = -1; }
-                else if (kind == MFMA_H5) {
+                else if (kind == MFMA_H5 && !general) {
+                    // K-chunks 0..4: kernel row f, lane group g = kx 0..3 (the row operands are re-used across rows);
+                    // chunk 5: column 4, lane group g = ky 0..3; chunk 6: tap (4,4) in lane group 0
+                    ch = chmap16(b);
+                    if (f < 5) { ky = f; kx = g; }
+                    else if (f == 5) { ky = g; kx = 4; }
+                    else if (g == 0) { ky = 4; kx = 4; }
+                } else if (kind == MFMA_H5) {
+                    // per PE p two K-chunks: 0: lane group g = kernel row g, words = kx 0..3;  1: row 4 + column 4 by four
+                    // translates of the pixel pattern {(0,0),(1,0),(2,0),(2,2)} (same scheme as MFMA_F5)
+                    const int fi = f >> 2, p = f & 3;
+                    static const int tr[4][2] = {{0, 4}, {2, 0}, {2, 1}, {2, 4}};
+                    static const int pt[4][2] = {{0, 0}, {1, 0}, {2, 0}, {2, 2}};
+                    ch = p + 4 * j;
+                    if (fi == 0) { ky = g; kx = i; }
+                    else {
+                        ky = tr[g][0] + pt[i][0]; kx = tr[g][1] + pt[i][1];
+                        const bool in_l = (ky == 4 && kx <= 4) || (kx == 4 && ky <= 4);
+                        if (!in_l || (g == 3 && i == 0)) ky = -1;
+                    }
+                }
+                else if (kind == MFMA_H5L && !general) { ky = f >> 1; kx = 4 * (f & 1) + g; ch = chmap16(b); if (kx > 4) ky = -1; }
+                else if (kind == MFMA_H5L) {
                     const int fi = f >> 2, p = f & 3;
                     ch = p + 4 * j;
                     if (fi == 0) { ky = g; kx = i; }
@@ -260,10 +282,10 @@ int sesrq_create(const sesrq_net_desc *d, sesrq_net **out) {
                     return 1;
                 }
             }
-            if (lp.mfma_kind == MFMA_F5) {
+            if (lp.mfma_kind == MFMA_F5 || (lp.mfma_kind == MFMA_H5 && k == L - 1)) {
                 for (int gen = 0; gen < 2; ++gen) {
                     std::vector<int> fr;
-                    pack_mfma_frags(l, MFMA_F5L, gen == 1, false, fr);
+                    pack_mfma_frags(l, lp.mfma_kind == MFMA_F5 ? MFMA_F5L : MFMA_H5L, gen == 1, k == L - 1, fr);
                     int4 **dst = gen ? &lp.d_afrag_f5l_general : &lp.d_afrag_f5l_merged;
                     if (hipMalloc((void **)dst, fr.size() * sizeof(int)) != hipSuccess ||
                         hipMemcpy(*dst, fr.data(), fr.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess) {
@@ -412,7 +434,7 @@ static int forward_impl(const sesrq_net *net, const void *in, int in_dtype, void
             const LayerPlan &lp = net->layers[k];
             const bool g = (k == 0) ? gen[0] : (k == 4 ? gen[4] : genh);
             f.l[k].afrag = g ? lp.d_afrag_general : lp.d_afrag_merged;
-            if (k == 0) f.l[k].afrag = g ? lp.d_afrag_f5l_general : lp.d_afrag_f5l_merged;
+            if (k == 0 || k == 4) f.l[k].afrag = g ? lp.d_afrag_f5l_general : lp.d_afrag_f5l_merged;
             f.l[k].Mf = lp.base.Mf; f.l[k].sh = lp.base.sh; f.l[k].z_next = lp.base.z_next;
             f.l[k].pad_next = (k < 4) ? net->layers[k + 1].base.pad_word : 0;
         }

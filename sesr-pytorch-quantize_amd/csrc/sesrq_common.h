@@ -11,7 +11,7 @@ namespace sesrq {
 
 enum Epi { EPI_MID = 0, EPI_PRERES = 1, EPI_LAST = 2 };
 enum Src { SRC_NHWC16 = 0, SRC_F32 = 1, SRC_I8 = 2 };
-enum MfmaKind { MFMA_NONE = 0, MFMA_H3 = 1, MFMA_H5 = 2, MFMA_F5 = 3, MFMA_H5P = 4, MFMA_F5L = 5 };   // F5L: 3-chunk first-layer image of the fused engine
+enum MfmaKind { MFMA_NONE = 0, MFMA_H3 = 1, MFMA_H5 = 2, MFMA_F5 = 3, MFMA_H5P = 4, MFMA_F5L = 5, MFMA_H5L = 6 };   // F5L / H5L: first/last-layer images in the fused engine's layout
 
 // Verified fast division of the input quantiser (sesrq_verify.hip): q0(x) with x pre-clamped to
 // [xlo, xhi] and x/s formed as fma(fma(-s, x*r, x), r, x*r); ok == 1 only after an exhaustive proof.
@@ -81,7 +81,7 @@ struct LayerPlan {
     int4 *d_afrag_general = nullptr; // device
     int4 *d_afrag_merged = nullptr;  // device
     int4 *d_afrag_pesplit = nullptr; // device: last layer with OC <= 4 (MFMA_H5P image), else NULL
-    int4 *d_afrag_f5l_general = nullptr, *d_afrag_f5l_merged = nullptr;   // device: layer 0, MFMA_F5L images (fused engine)
+    int4 *d_afrag_f5l_general = nullptr, *d_afrag_f5l_merged = nullptr;   // device: MFMA_F5L / MFMA_H5L images (fused engine)
     std::string engine_dot4, engine_mfma;
     ConvArgs base;           // constant fields prefilled
     // static saturation analysis (per layer)

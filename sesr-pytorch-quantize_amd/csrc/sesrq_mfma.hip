@@ -417,16 +417,15 @@ __global__ __launch_bounds__(256) void mfma_h5_kernel(const ConvArgs a) {
     if constexpr (BIASED) { ac.x += MAGIC_I; ac.y += MAGIC_I; ac.z += MAGIC_I; ac.w += MAGIC_I; }
     const float zlo = a.relu ? fmaxf(EPI == EPI_LAST ? a.z_out : a.z_next, -128.f) : -128.f;
     const int gx = x0 + 16 * w + n;
-    // merged: frag (ky, h): lane group g = tap kx = 4h + g  (h = 1: only kx = 4 carries weights)
-    // general, per PE p two K-chunks:  f = 0: group g = ky 0..3, words = kx 0..3
-    //                                  f = 1: g0 = (ky 4, kx 0..3)  g1 = (ky 0..3, kx 4)  g2 = (4,4)  g3 = none
-    constexpr int NF = GENERAL ? 8 : 10;
+    // merged: K-chunks 0..4 = kernel row f, lane group g = kx 0..3;  5 = column 4, lane group g = ky 0..3;  6 = tap (4,4)
+    // general, per PE p two K-chunks:  0: group g = ky 0..3, words = kx 0..3
+    //                                  1: row 4 + column 4: pixel pattern {(0,0),(1,0),(2,0),(2,2)} translated by
+    //                                     (0,4) (2,0) (2,1) (2,4) for lane groups 0..3   (pack_mfma_frags, MFMA_H5)
+    constexpr int NF = GENERAL ? 8 : 7;
     v4i A[NF];
 #pragma unroll
     for (int f = 0; f < NF; ++f) A[f] = ld_frag(fr + 4 + f * 64 + l);
-    int off1[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) off1[i] = (g == 0) ? 4 * SW + i : (g == 1 ? i * SW + 4 : 4 * SW + 4);
+    const int tr1 = (g == 0 ? 0 : 2) * SW + (g == 0 ? 4 : (g == 1 ? 0 : (g == 2 ? 1 : 4)));    // chunk-1 translation, in pixels
     LastStore ls;
     if constexpr (EPI == EPI_LAST) ls.init(a, n_img, g, gx);
     v4i AR[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
@@ -438,37 +437,34 @@ __global__ __launch_bounds__(256) void mfma_h5_kernel(const ConvArgs a) {
         RowIO io;
         if constexpr (EPI != EPI_LAST) io = make_rowio(a, n_img, y0, gx, g);
         if constexpr (!GENERAL) {
-            const int col = 16 * w + n + g;
+            const int col = 16 * w + n + g, colc = 16 * w + n + 4;
             const v4i zero = {0, 0, 0, 0};
             const v4i acc0 = (MODE == HYB) ? zero : (v4i){ac.x, ac.y, ac.z, ac.w};
             const int *t32 = reinterpret_cast<const int *>(tile);
             const int cb = (16 * w + n) * 4 + a.risky_pe;       // HYB: word risky_pe of column (16w + n), row 0
-            v4i B[5][2];
+            v4i B[5];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                B[r][0] = ld_frag(tile + r * SW + col);
-                B[r][1] = ld_frag(tile + r * SW + col + 4);
-            }
+            for (int r = 0; r < 4; ++r) B[r] = ld_frag(tile + r * SW + col);
 #pragma unroll
             for (int y4 = 0; y4 < MTH; y4 += 4) {
                 int s4[4][4];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int y = y4 + r;
-                    B[(y + 4) % 5][0] = ld_frag(tile + (y + 4) * SW + col);
-                    B[(y + 4) % 5][1] = ld_frag(tile + (y + 4) * SW + col + 4);
+                    B[(y + 4) % 5] = ld_frag(tile + (y + 4) * SW + col);
+                    const v4i C5 = ld_frag(tile + (y + g) * SW + colc);      // column 4: lane group g = kernel row g
+                    const v4i C6 = ld_frag(tile + (y + 4) * SW + colc);      // tap (4,4)
                     v4i acc[MODE == HYB ? 2 : 1];
                     acc[0] = acc0;
 #pragma unroll
-                    for (int ky = 0; ky < 5; ++ky) {
-                        acc[0] = mfma(A[ky * 2 + 0], B[(y + ky) % 5][0], acc[0]);
-                        acc[0] = mfma(A[ky * 2 + 1], B[(y + ky) % 5][1], acc[0]);
-                    }
+                    for (int ky = 0; ky < 5; ++ky) acc[0] = mfma(A[ky], B[(y + ky) % 5], acc[0]);
+                    acc[0] = mfma(A[5], C5, acc[0]);
+                    acc[0] = mfma(A[6], C6, acc[0]);
                     if constexpr (MODE == HYB) {
                         const int o0 = cb + (y + g) * SW * 4;          // K-chunk 0: row y+g, columns +0..3
                         const v4i b0 = {t32[o0], t32[o0 + 4], t32[o0 + 8], t32[o0 + 12]};
-                        const int ob = cb + y * SW * 4;                // K-chunk 1: per-lane tap offsets off1[]
-                        const v4i b1 = {t32[ob + off1[0] * 4], t32[ob + off1[1] * 4], t32[ob + off1[2] * 4], t32[ob + off1[3] * 4]};
+                        const int ob = cb + (y * SW + tr1) * 4;        // K-chunk 1: translated pixel pattern
+                        const v4i b1 = {t32[ob], t32[ob + SW * 4], t32[ob + 2 * SW * 4], t32[ob + (2 * SW + 2) * 4]};
                         acc[1] = mfma(AR[0], b0, zero);
                         acc[1] = mfma(AR[1], b1, acc[1]);
                     }
@@ -498,8 +494,8 @@ __global__ __launch_bounds__(256) void mfma_h5_kernel(const ConvArgs a) {
                         { const v4i b = gather4<3>(P0, P1, P2, P3); acc[3] = mfma(A[3], b, zero); }
                     }
                     {
-                        const int4 *base = tile + y * SW + col;
-                        const int4 P0 = base[off1[0]], P1 = base[off1[1]], P2 = base[off1[2]], P3 = base[off1[3]];
+                        const int4 *base = tile + y * SW + col + tr1;
+                        const int4 P0 = base[0], P1 = base[SW], P2 = base[2 * SW], P3 = base[2 * SW + 2];
                         { const v4i b = gather4<0>(P0, P1, P2, P3); acc[0] = mfma(A[4], b, acc[0]); }
                         { const v4i b = gather4<1>(P0, P1, P2, P3); acc[1] = mfma(A[5], b, acc[1]); }
                         { const v4i b = gather4<2>(P0, P1, P2, P3); acc[2] = mfma(A[6], b, acc[2]); }
