@@ -208,7 +208,11 @@ __device__ __forceinline__ void store_rows4(__amdgpu_buffer_rsrc_t rs, const Row
 // workgroup can keep the loads of its NEXT tile in flight while it computes the current one:
 //   load():  all buffer loads of a thread issued back to back (out-of-range -> 0)
 //   store(): pad word selected in for pixels outside the frame, then written to LDS
-template <int SH, int SW, int R>
+//   PW == 0: LDS image = SH x SW pixels of 16 bytes (merged / hybrid kernels: one ds_read_b128 = one pixel)
+//   PW  > 0: PE-planar image for the per-PE (general) kernels: row pitch 4*PW dwords, dword [row][p][col] = word p
+//            (the 4 channels of PE p) of the pixel -- a lane's MFMA operand (4 pixels of ONE PE) is then read
+//            directly by dword loads with immediate plane offsets, no register shuffling.
+template <int SH, int SW, int R, int PW = 0>
 struct StageNHWC16 {
     static constexpr int NIT = (SH * SW + 255) / 256;
     v4u v[NIT];
@@ -259,7 +263,16 @@ struct StageNHWC16 {
             const int i = tid + it * 256;
             const v4u pad = {pw, pw, pw, pw};
             const v4u t = ok[it] ? v[it] : pad;
-            if (i < SH * SW) tile[i] = make_int4((int)t[0], (int)t[1], (int)t[2], (int)t[3]);
+            if constexpr (PW == 0) {
+                if (i < SH * SW) tile[i] = make_int4((int)t[0], (int)t[1], (int)t[2], (int)t[3]);
+            } else {
+                int *tw = reinterpret_cast<int *>(tile);
+                const int row = i / SW, col = i - row * SW;
+                if (i < SH * SW) {
+                    int *d = tw + row * (4 * PW) + col;
+                    d[0] = (int)t[0]; d[PW] = (int)t[1]; d[2 * PW] = (int)t[2]; d[3 * PW] = (int)t[3];
+                }
+            }
         }
     }
 };
@@ -332,6 +345,7 @@ __global__ __launch_bounds__(256) void mfma_h3_kernel(const ConvArgs a) {
     constexpr bool GENERAL = MODE == GEN_STD || MODE == GEN_ANY;
     constexpr int SW = MTW + 4;                      // 1 left halo + 64 + 1 right halo + over-read
     constexpr int SH = MTH + 2 + (MODE != MERGED ? 1 : 0);  // per-PE chains read row y+3 with zero weights
+    constexpr int PW = GENERAL ? SW : 0;             // planar image: row pitch 4*68 = 272 dwords = 16 mod 64 banks
     __shared__ int4 buf0[SH * SW], buf1[SH * SW];
     const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, n = l & 15, g = l >> 4;
     const int x0 = blockIdx.x * MTW, n_img = blockIdx.z;
@@ -382,14 +396,15 @@ __global__ __launch_bounds__(256) void mfma_h3_kernel(const ConvArgs a) {
                 int s4[4][4];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int4 *row = tile + (y4 + r + g) * SW + col;     // lane group g = kernel row ky
-                    const int4 P0 = row[0], P1 = row[1], P2 = row[2], P3 = row[3];
+                    const int *row = reinterpret_cast<const int *>(tile) + (y4 + r + g) * (4 * PW) + col;   // lane group g = kernel row ky
                     const v4i zero = {0, 0, 0, 0};
                     v4i acc[4];
-                    { const v4i b = gather4<0>(P0, P1, P2, P3); acc[0] = mfma(A[0], b, zero); }
-                    { const v4i b = gather4<1>(P0, P1, P2, P3); acc[1] = mfma(A[1], b, zero); }
-                    { const v4i b = gather4<2>(P0, P1, P2, P3); acc[2] = mfma(A[2], b, zero); }
-                    { const v4i b = gather4<3>(P0, P1, P2, P3); acc[3] = mfma(A[3], b, zero); }
+#pragma unroll
+                    for (int p = 0; p < 4; ++p) {
+                        const int *q = row + p * PW;                       // plane p: 4 horizontally adjacent pixels of PE p
+                        const v4i b = {q[0], q[1], q[2], q[3]};
+                        acc[p] = mfma(A[p], b, zero);
+                    }
                     finish_sums<MODE>(s4[r], acc, ac, a);
                 }
                 emit_rows4<EPI, false, BIASED>(s4, a, io, y4, zlo);
@@ -397,7 +412,7 @@ __global__ __launch_bounds__(256) void mfma_h3_kernel(const ConvArgs a) {
         }
     };
 #define SESRQ_COMPUTE(B) compute(B, y0);
-    using Stage = StageNHWC16<SH, SW, 1>;
+    using Stage = StageNHWC16<SH, SW, 1, PW>;
     SESRQ_TILE_WALK(Stage, buf0, buf1, SESRQ_COMPUTE)
 #undef SESRQ_COMPUTE
 }
@@ -408,7 +423,9 @@ __global__ __launch_bounds__(256) void mfma_h5_kernel(const ConvArgs a) {
     constexpr bool GENERAL = MODE == GEN_STD || MODE == GEN_ANY;
     constexpr int SW = MTW + 8;          // 2 + 64 + 2 halo, + over-read of the kx = 4..7 group
     constexpr int SH = MTH + 4;
-    __shared__ int4 buf0[SH * SW], buf1[SH * SW];
+    constexpr int PW = GENERAL ? SW + 4 : 0;     // planar image: row pitch 4*76 = 304 dwords = 48 mod 64 banks
+    constexpr int RP = 4 * PW;
+    __shared__ int4 buf0[GENERAL ? SH * PW : SH * SW], buf1[GENERAL ? SH * PW : SH * SW];
     const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, n = l & 15, g = l >> 4;
     const int x0 = blockIdx.x * MTW, n_img = blockIdx.z;
     const int4 *fr = a.afrag;
@@ -425,7 +442,7 @@ __global__ __launch_bounds__(256) void mfma_h5_kernel(const ConvArgs a) {
     v4i A[NF];
 #pragma unroll
     for (int f = 0; f < NF; ++f) A[f] = ld_frag(fr + 4 + f * 64 + l);
-    const int tr1 = (g == 0 ? 0 : 2) * SW + (g == 0 ? 4 : (g == 1 ? 0 : (g == 2 ? 1 : 4)));    // chunk-1 translation, in pixels
+    const int tr1 = (g == 0 ? 0 : 2) * (GENERAL ? RP : SW) + (g == 0 ? 4 : (g == 1 ? 0 : (g == 2 ? 1 : 4)));    // chunk-1 translation (pixels; planar: dwords)
     LastStore ls;
     if constexpr (EPI == EPI_LAST) ls.init(a, n_img, g, gx);
     v4i AR[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
@@ -485,21 +502,16 @@ __global__ __launch_bounds__(256) void mfma_h5_kernel(const ConvArgs a) {
                     const int y = y4 + r;
                     const v4i zero = {0, 0, 0, 0};
                     v4i acc[4];
-                    {
-                        const int4 *row = tile + (y + g) * SW + col;
-                        const int4 P0 = row[0], P1 = row[1], P2 = row[2], P3 = row[3];
-                        { const v4i b = gather4<0>(P0, P1, P2, P3); acc[0] = mfma(A[0], b, zero); }
-                        { const v4i b = gather4<1>(P0, P1, P2, P3); acc[1] = mfma(A[1], b, zero); }
-                        { const v4i b = gather4<2>(P0, P1, P2, P3); acc[2] = mfma(A[2], b, zero); }
-                        { const v4i b = gather4<3>(P0, P1, P2, P3); acc[3] = mfma(A[3], b, zero); }
-                    }
-                    {
-                        const int4 *base = tile + y * SW + col + tr1;
-                        const int4 P0 = base[0], P1 = base[SW], P2 = base[2 * SW], P3 = base[2 * SW + 2];
-                        { const v4i b = gather4<0>(P0, P1, P2, P3); acc[0] = mfma(A[4], b, acc[0]); }
-                        { const v4i b = gather4<1>(P0, P1, P2, P3); acc[1] = mfma(A[5], b, acc[1]); }
-                        { const v4i b = gather4<2>(P0, P1, P2, P3); acc[2] = mfma(A[6], b, acc[2]); }
-                        { const v4i b = gather4<3>(P0, P1, P2, P3); acc[3] = mfma(A[7], b, acc[3]); }
+                    const int *tw = reinterpret_cast<const int *>(tile);
+                    const int *c0 = tw + (y + g) * RP + col;            // chunk 0: row y+g, 4 adjacent pixels
+                    const int *c1 = tw + y * RP + col + tr1;            // chunk 1: translated pattern (0,0) (1,0) (2,0) (2,2)
+#pragma unroll
+                    for (int p = 0; p < 4; ++p) {
+                        const int *q0 = c0 + p * PW, *q1 = c1 + p * PW;
+                        const v4i b0 = {q0[0], q0[1], q0[2], q0[3]};
+                        const v4i b1 = {q1[0], q1[RP], q1[2 * RP], q1[2 * RP + 2]};
+                        acc[p] = mfma(A[p], b0, zero);
+                        acc[p] = mfma(A[4 + p], b1, acc[p]);
                     }
                     finish_sums<MODE>(s4[r], acc, ac, a);
                     if constexpr (EPI == EPI_LAST) {
@@ -511,7 +523,7 @@ __global__ __launch_bounds__(256) void mfma_h5_kernel(const ConvArgs a) {
         }
     };
 #define SESRQ_COMPUTE(B) compute(B, y0);
-    using Stage = StageNHWC16<SH, SW, 2>;
+    using Stage = StageNHWC16<SH, SW, 2, PW>;
     SESRQ_TILE_WALK(Stage, buf0, buf1, SESRQ_COMPUTE)
 #undef SESRQ_COMPUTE
 }
