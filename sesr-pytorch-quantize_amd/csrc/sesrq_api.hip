@@ -83,7 +83,8 @@ static bool saturation_free(const sesrq_layer_desc &d, int zc, int acc_bits, int
 // fragment f carries W[ocmap(m)][ch][ky][kx] for the (ky, kx, ch) the kernel's B operand puts in
 // the same (g, b) slot -- the tables below are the single source of truth for both sides
 // (kernels: sesrq_mfma.hip).
-static void pack_mfma_frags(const sesrq_layer_desc &d, int kind, bool general, bool last, std::vector<int> &out) {
+// zero_pe >= 0: the channels of that PE carry no weights (hybrid kernels: the chain of the other three PEs)
+static void pack_mfma_frags(const sesrq_layer_desc &d, int kind, bool general, bool last, std::vector<int> &out, int zero_pe = -1) {
     const int taps = d.k * d.k;
     int F = 0;
     switch (kind) {
@@ -169,7 +170,7 @@ static void pack_mfma_frags(const sesrq_layer_desc &d, int kind, bool general, b
                 }
                 const int oc = ocmap(m);
                 int w = 0;
-                if (ky >= 0 && ky < d.k && kx >= 0 && kx < d.k && ch >= 0 && ch < d.ic && oc < d.oc)
+                if (ky >= 0 && ky < d.k && kx >= 0 && kx < d.k && ch >= 0 && ch < d.ic && oc < d.oc && (ch & 3) != zero_pe)
                     w = d.w[((size_t)oc * d.ic + ch) * taps + ky * d.k + kx];
                 bytes[((size_t)f * 64 + lane) * 16 + b] = (signed char)w;
             }
@@ -282,6 +283,16 @@ int sesrq_create(const sesrq_net_desc *d, sesrq_net **out) {
                     return 1;
                 }
             }
+            if (lp.general && __builtin_popcount(lp.risky_mask) == 1) {      // hybrid kernels: merged chain without the risky PE
+                std::vector<int> fr;
+                pack_mfma_frags(l, lp.mfma_kind, false, k == L - 1, fr, __builtin_ctz(lp.risky_mask));
+                if (hipMalloc((void **)&lp.d_afrag_others, fr.size() * sizeof(int)) != hipSuccess ||
+                    hipMemcpy(lp.d_afrag_others, fr.data(), fr.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess) {
+                    set_error("sesrq_create: device upload failed");
+                    sesrq_destroy(net);
+                    return 1;
+                }
+            }
             if (lp.mfma_kind == MFMA_F5 || (lp.mfma_kind == MFMA_H5 && k == L - 1)) {
                 for (int gen = 0; gen < 2; ++gen) {
                     std::vector<int> fr;
@@ -348,6 +359,7 @@ void sesrq_destroy(sesrq_net *net) {
         if (lp.d_afrag_general) (void)hipFree(lp.d_afrag_general);
         if (lp.d_afrag_merged) (void)hipFree(lp.d_afrag_merged);
         if (lp.d_afrag_pesplit) (void)hipFree(lp.d_afrag_pesplit);
+        if (lp.d_afrag_others) (void)hipFree(lp.d_afrag_others);
         if (lp.d_afrag_f5l_general) (void)hipFree(lp.d_afrag_f5l_general);
         if (lp.d_afrag_f5l_merged) (void)hipFree(lp.d_afrag_f5l_merged);
     }
@@ -482,8 +494,8 @@ static int forward_impl(const sesrq_net *net, const void *in, int in_dtype, void
         if (use_mfma) {
             a.afrag = eff.general ? lp.d_afrag_general : lp.d_afrag_merged;
             // exactly one PE can saturate (and nothing forces the full per-PE path): merged chain + that PE's chain
-            const bool one_pe = lp.general && !net->force_general && !dbg && __builtin_popcount(lp.risky_mask) == 1;
-            if (one_pe) { a.afrag = lp.d_afrag_merged; a.afrag2 = lp.d_afrag_general; a.risky_pe = __builtin_ctz(lp.risky_mask); }
+            const bool one_pe = lp.general && !net->force_general && !dbg && lp.d_afrag_others && net->acc_bits == 18 && net->add_bits == 20;
+            if (one_pe) { a.afrag = lp.d_afrag_others; a.afrag2 = lp.d_afrag_general; a.risky_pe = __builtin_ctz(lp.risky_mask); }
             if (lp.d_afrag_pesplit) a.afrag = lp.d_afrag_pesplit;
             if (launch_mfma(lp, a, src, epi, eff.general, st, one_pe)) return 1;
         } else if (launch_dot4(eff, a, src, epi, st)) return 1;

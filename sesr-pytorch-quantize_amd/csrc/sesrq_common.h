@@ -32,7 +32,7 @@ struct ConvArgs {
     const float *anchor;     // EPI_LAST: fp32 input frame (N,C,H,W) added, nearest-upsampled, to out_f; or NULL
     const int *wpk;          // dot4: packed weights [tap][OCP][4] dwords (see pack_weights)
     const int4 *afrag;       // mfma: [4] add-constant words (row order) + A fragments [F][64] (pack_mfma_frags)
-    const int4 *afrag2;      // mfma hybrid mode: the per-PE (general) fragment image; risky_pe selects the chain
+    const int4 *afrag2;      // mfma hybrid mode: afrag = merged image WITHOUT the risky PE, afrag2 = per-PE (general) image; risky_pe selects its chain
     int risky_pe;
     int *dbg_pe;             // (N,4,OC,H,W) int32 or NULL
     int *dbg_add;            // (N,OC,H,W) int32 or NULL
@@ -81,6 +81,7 @@ struct LayerPlan {
     int4 *d_afrag_general = nullptr; // device
     int4 *d_afrag_merged = nullptr;  // device
     int4 *d_afrag_pesplit = nullptr; // device: last layer with OC <= 4 (MFMA_H5P image), else NULL
+    int4 *d_afrag_others = nullptr;  // device: exactly one risky PE: merged image with that PE's channels zeroed, else NULL
     int4 *d_afrag_f5l_general = nullptr, *d_afrag_f5l_merged = nullptr;   // device: MFMA_F5L / MFMA_H5L images (fused engine)
     std::string engine_dot4, engine_mfma;
     ConvArgs base;           // constant fields prefilled

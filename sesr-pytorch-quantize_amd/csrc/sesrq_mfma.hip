@@ -155,9 +155,10 @@ __device__ __forceinline__ void finish_sums(int s[4], const v4i *acc, const int4
         if constexpr (MODE == MERGED) {
             s[i] = acc[0][i];       // add constant already in the accumulator (C-in)
         } else if constexpr (MODE == HYB) {
-            // acc[0] = sum over ALL PEs (none of the other three can saturate: load-time proof), acc[1] = the risky PE
-            const int t = acc[0][i] + (clampi3(acc[1][i], -131072, 131071) - acc[1][i]);
-            s[i] = clampi3(t, -524288, 524287) + acv[i];
+            // acc[0] = add constant + the three PEs that cannot saturate (load-time proof: each stays inside 18 bits, so their
+            // 18-bit clamps are no-ops), acc[1] = the risky PE.  |three safe sums + one clamped sum| <= 3*131072 + 131072
+            // = 2^19: the 20-bit adder clamp cannot fire either (quan_func.py:437 is a no-op here).
+            s[i] = acc[0][i] + clampi3(acc[1][i], -131072, 131071);
         } else if constexpr (MODE == GEN_STD) {
             const int t = clampi3(acc[0][i], -131072, 131071) + clampi3(acc[1][i], -131072, 131071) +
                           clampi3(acc[2][i], -131072, 131071) + clampi3(acc[3][i], -131072, 131071);
@@ -365,7 +366,7 @@ __global__ __launch_bounds__(256) void mfma_h3_kernel(const ConvArgs a) {
         if constexpr (!GENERAL) {
             const int col = 16 * w + n + g;
             const v4i zero = {0, 0, 0, 0};
-            const v4i acc0 = (MODE == HYB) ? zero : (v4i){ac.x, ac.y, ac.z, ac.w};
+            const v4i acc0 = {ac.x, ac.y, ac.z, ac.w};
             const int *t32 = reinterpret_cast<const int *>(tile);
             const int rbase = (g * SW + 16 * w + n) * 4 + a.risky_pe;      // HYB: word risky_pe of pixel (row g, col)
             v4i B0 = ld_frag(tile + col), B1 = ld_frag(tile + SW + col);
@@ -456,7 +457,7 @@ __global__ __launch_bounds__(256) void mfma_h5_kernel(const ConvArgs a) {
         if constexpr (!GENERAL) {
             const int col = 16 * w + n + g, colc = 16 * w + n + 4;
             const v4i zero = {0, 0, 0, 0};
-            const v4i acc0 = (MODE == HYB) ? zero : (v4i){ac.x, ac.y, ac.z, ac.w};
+            const v4i acc0 = {ac.x, ac.y, ac.z, ac.w};
             const int *t32 = reinterpret_cast<const int *>(tile);
             const int cb = (16 * w + n) * 4 + a.risky_pe;       // HYB: word risky_pe of column (16w + n), row 0
             v4i B[5];
@@ -739,7 +740,7 @@ __global__ __launch_bounds__(256) void mfma_f5_kernel(const ConvArgs a) {
                         acc[p] = mfma(A[1][p], B1, acc[p]);
                     }
                 } else {
-                    const v4i acc0 = (MODE == HYB) ? zero : (v4i){ac.x, ac.y, ac.z, ac.w};
+                    const v4i acc0 = {ac.x, ac.y, ac.z, ac.w};
                     acc[0] = mfma(A[0][0], B0, acc0);
                     acc[0] = mfma(A[1][0], B1, acc[0]);
                     if constexpr (MODE == HYB) {       // same B operands, A masked to the risky PE's channel
