@@ -13,9 +13,10 @@
 //
 //   merged  (load-time proof: no 18/20-bit saturation possible): a lane group = one tap,
 //           16 bytes = the 16 channels; rows are re-used across ky (register rotation).
+//   hybrid  (exactly one PE can saturate): the merged chain over the other three PEs + that PE's chain.
 //   general (per-PE sums must be clamped separately, myQL/quan_func.py:370): a lane's 16
-//           bytes = 4 taps x the 4 channels of ONE PE; one MFMA chain per PE; the operand is
-//           word p of four staged pixels (PE-major channel order makes that a register pick).
+//           bytes = 4 taps x the 4 channels of ONE PE; one MFMA chain per PE; the kernels stage a
+//           PE-planar LDS image so that the operand is four plain dword reads.
 //
 // Output rows are ordered so that a lane's 4 accumulators are the 4 bytes of word g of the
 // NHWC16 (PE-major) output pixel.  Four image rows are produced per step; a 4x4 transpose
