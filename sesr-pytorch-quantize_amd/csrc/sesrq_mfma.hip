@@ -61,14 +61,17 @@ __device__ __forceinline__ unsigned epi_preres(const int s[4], unsigned rcword, 
     v2f v01, v23;
     requant4<BIASED>(s, a.Mf, a.sh, -128.f, v01, v23);
     const unsigned rcx = rcword ^ 0x80808080u;                 // rc + 128 as unsigned bytes
-    const v2f k128 = {128.f, 128.f};
-    // ic = rint(clamp(t - 128)) ; u = rc + ic + 256 = (rc + 128) + ic + 128   (all exact small integers)
-    const v2f i01 = {rintf(med3(v01[0], -128.f, 127.f)), rintf(med3(v01[1], -128.f, 127.f))};
-    const v2f i23 = {rintf(med3(v23[0], -128.f, 127.f)), rintf(med3(v23[1], -128.f, 127.f))};
-    const v2f r01 = {(float)(rcx & 0xffu), (float)((rcx >> 8) & 0xffu)}, r23 = {(float)((rcx >> 16) & 0xffu), (float)(rcx >> 24)};
-    const v2f u01 = (r01 + k128) + i01, u23 = (r23 + k128) + i23;
-    const v2f M2 = {a.Mres, a.Mres}, sh2 = {a.shres, a.shres}, z2 = {a.z_merge, a.z_merge};
-    const v2f w01 = __builtin_elementwise_fma(u01 * M2, sh2, z2), w23 = __builtin_elementwise_fma(u23 * M2, sh2, z2);
+    // ic = rint(clamp(t - 128)) ; u = rc + ic + 256 = (rc + 128) + (ic + 128), an integer in [0, 510].
+    // Adding 1.5*2^23 + 128 rounds to nearest even and leaves ic + 128 in the low mantissa bits; a plain integer add of the
+    // rc byte then gives the bit pattern of the float 1.5*2^23 + u, which is exactly what the cvt-free requant
+    // (requant4<true>) takes as its input: no v_rndne, no byte->float converts, no float adds.
+    const v2f mg128 = {MAGIC + 128.f, MAGIC + 128.f};
+    v2f c01 = {med3(v01[0], -128.f, 127.f), med3(v01[1], -128.f, 127.f)}, c23 = {med3(v23[0], -128.f, 127.f), med3(v23[1], -128.f, 127.f)};
+    c01 = c01 + mg128; c23 = c23 + mg128;
+    const int u[4] = {(int)(fbits(c01[0]) + (rcx & 0xffu)), (int)(fbits(c01[1]) + ((rcx >> 8) & 0xffu)),
+                      (int)(fbits(c23[0]) + ((rcx >> 16) & 0xffu)), (int)(fbits(c23[1]) + (rcx >> 24))};
+    v2f w01, w23;
+    requant4<true>(u, a.Mres, a.shres, a.z_merge, w01, w23);
     return round_pack(w01, w23, -128.f, 127.f);
 }
 
