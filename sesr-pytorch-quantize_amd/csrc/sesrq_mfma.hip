@@ -671,16 +671,16 @@ struct StageFrame {
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
             const int i = tid + it * 256;
-            int word = 0;
+            unsigned b[4];
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
-                int q;
                 if constexpr (SRC == SRC_F32)
-                    q = (int)quantize_in(__builtin_bit_cast(float, raw[it][c]), a.s_in, a.z_in, a.fd);
+                    b[c] = quantize_in_bits(__builtin_bit_cast(float, raw[it][c]), a.s_in, a.z_in, a.fd);
                 else
-                    q = (int)raw[it][c];
-                if (c < a.ic) word |= (q & 0xff) << (8 * c);
+                    b[c] = raw[it][c];
+                if (c >= a.ic) b[c] = 0;
             }
+            int word = (int)pack_lo_bytes(b[0], b[1], b[2], b[3]);
             if (!ok[it]) word = a.pad_word;
             if (i < SH * SWP) cpw[(i / SWP) * PITCH + (i % SWP)] = word;
         }

@@ -32,6 +32,19 @@ __device__ __forceinline__ float quantize_in(float x, float s, float z, const Fa
     }
     return med3(rintf(__fadd_rn(t, z)), -128.f, 127.f);
 }
+// same value as the low byte (two's complement) of the returned word: clamp the un-rounded value, then round to nearest
+// even by adding 1.5 * 2^23 (clamp and rint commute for integer bounds) -- no v_rndne / v_cvt_i32
+__device__ __forceinline__ unsigned quantize_in_bits(float x, float s, float z, const FastDiv &fd) {
+    float t;
+    if (fd.ok) {
+        const float xc = med3(x, fd.xlo, fd.xhi);
+        const float q = __fmul_rn(xc, fd.r);
+        t = __builtin_fmaf(__builtin_fmaf(-s, q, xc), fd.r, q);
+    } else {
+        t = __fdiv_rn(x, s);
+    }
+    return __builtin_bit_cast(unsigned, __fadd_rn(med3(__fadd_rn(t, z), -128.f, 127.f), 12582912.f));
+}
 
 // general path: the MFMA operand of PE P = word P of four staged pixels.  Two v_pk_mov_b32 build the
 // four consecutive operand registers (each moves one word out of two different source pairs) instead of
