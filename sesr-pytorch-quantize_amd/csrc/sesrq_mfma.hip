@@ -39,7 +39,7 @@
 namespace sesrq {
 
 constexpr int MTW = 64;   // tile width : 4 waves x 16 pixels
-constexpr int MTH = 16;   // tile height: rows walked by every wave (multiple of 4)
+constexpr int MTH = 8;    // tile height: rows walked by every wave (multiple of 4); 8 beats 12 and 16 on 1080p (latency hiding vs halo)
 
 // hidden layer: q = clamp8(rint(relu(t) + z_next))            (myQL/quan_func.py:280)
 template <bool BIASED>
@@ -283,7 +283,7 @@ struct StageNHWC16 {
 };
 
 // Persistent tile walk: a workgroup owns a 64-column strip and `a.chunk_tiles` vertically adjacent
-// 16-row tiles; tile k+1 is loaded (registers) while tile k is computed out of the other LDS buffer.
+// MTH-row tiles; tile k+1 is loaded (registers) while tile k is computed out of the other LDS buffer.
 // Diagnostic build only (-DSESRQ_STAMPS): wave 0 of every workgroup records s_memrealtime /
 // s_memtime at the phase boundaries into a buffer no other code reads (guide §7, in-kernel stamps).
 #ifdef SESRQ_STAMPS
