@@ -331,13 +331,14 @@ def test_x2_anchor_add(eng):
 
 def test_randomised_shapes_against_c_oracle():
     """Stress the tile / chunk / strip boundaries of the persistent kernels: random frame sizes (around multiples of
-    16 rows and 64 columns, tiny and tall), batches, all three topologies, merged / hybrid / general kernels."""
+    8 / 16 rows and 64 columns, tiny and tall), batches, all three topologies, merged / hybrid / general kernels.
+    SESRQ_STRESS_TRIALS=<n> runs more trials (same generator, longer sequence)."""
     from oracle import c_oracle as CO
     rng = np.random.default_rng(2024)
-    heights = [15, 16, 17, 31, 32, 33, 47, 48, 49, 63, 64, 65, 95, 97, 129, 255, 257, 300]
+    heights = [1, 3, 7, 8, 9, 15, 16, 17, 23, 24, 25, 31, 32, 33, 47, 48, 49, 63, 64, 65, 95, 97, 129, 255, 257, 300]
     widths = [1, 2, 15, 16, 17, 63, 64, 65, 127, 128, 129, 191, 193, 250]
     kinds = ["sesr_x4", "sesr_x2", "nrdm"]
-    for trial in range(24):
+    for trial in range(int(os.environ.get("SESRQ_STRESS_TRIALS", "24"))):
         kind = kinds[trial % 3]
         hard = (trial // 3) % 2 == 1
         net = O.synth_net(kind, 100 + trial, hard=hard)
