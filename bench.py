@@ -52,7 +52,7 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--batch", type=int, default=1, help="frames per step per GPU")
-    ap.add_argument("--streams", type=int, default=3,
+    ap.add_argument("--streams", type=int, default=2,
                     help="HIP streams the steps are enqueued on round-robin (frames are independent; each stream has "
                          "its own workspace and output buffer) -- fills the launch/prologue/tail gaps of the 5 kernels")
     ap.add_argument("--workload", default="sesr_x2_1080p", choices=sorted(WORKLOADS))
