@@ -173,7 +173,8 @@ def main():
                   "vs_baseline": None, "dtype": "i8", "data": "synthetic",
                   "config": {"workload": desc, "name": args.workload, "frames_per_step_per_gpu": B, "streams": NS, "in": [B, cin, H, W],
                              "out": list(eng.out_shape(B, H, W)), "input_dtype": "f32", "output_dtype": "i8",
-                             "weights": f"reference random-init net, calibrated by the reference ({fixture})",
+                             "weights": ("reference random-init net, calibrated by the reference" if "rand" in fixture else
+                                         "reference checkpoint, quantised and calibrated by the reference") + f" ({fixture})",
                              "sharding": f"frames x{world}, no collective", "engines": eng.layer_engines()},
                   "roofline": roofline, "cpu_baseline": cpu, "parity": parity}
     grp.close()
