@@ -24,19 +24,39 @@
 extern "C" {
 #endif
 
-#define SESRQ_VERSION 1
+#define SESRQ_VERSION 2
 #define SESRQ_MAX_LAYERS 16
 #define SESRQ_MAX_CH 16
 
 /* data types of the frame buffers handed over the boundary (always NCHW, like the reference) */
 enum { SESRQ_F32 = 0, SESRQ_I8 = 1 };
 
-/* kernel families (sesrq_set_option(net, SESRQ_OPT_ENGINE, ...)) */
-enum { SESRQ_ENGINE_AUTO = 0, SESRQ_ENGINE_DOT4 = 1, SESRQ_ENGINE_MFMA = 2, SESRQ_ENGINE_FUSED = 3 };
-enum { SESRQ_OPT_ENGINE = 1, SESRQ_OPT_FORCE_GENERAL = 2, SESRQ_OPT_EXACT_DIV = 3,
-       /* add the nearest-upsampled fp32 input frame to the fp32 output (the x2 "anchor" of the reference's eval
-        * loop, test.py:148-155: gfake + inps_x2); needs Cin == Cout and an fp32 input; int8 output unaffected */
-       SESRQ_OPT_ANCHOR_ADD = 4 };
+/* kernel families (sesrq_options.engine): AUTO = MFMA kernels where a layer shape has one, else dot4 */
+enum { SESRQ_ENGINE_AUTO = 0, SESRQ_ENGINE_DOT4 = 1, SESRQ_ENGINE_MFMA = 2 };
+
+/* Options of a net, fixed at sesrq_create (there is no setter: a created net is immutable).
+ * sesrq_default_options() fills the defaults; a NULL options pointer means the defaults too. */
+typedef struct sesrq_options {
+    int32_t engine;          /* SESRQ_ENGINE_*                                                        (default AUTO) */
+    int32_t force_general;   /* 1: always run the per-PE clamp path, even where a load-time proof says it is a no-op */
+    int32_t exact_div;       /* 1: IEEE division in the input quantiser even if the fast form is proven         */
+    int32_t anchor_add;      /* 1: add the nearest-upsampled fp32 input frame to the fp32 output (the x2 "anchor" of the
+                              * reference's eval loop, test.py:148-155: gfake + inps_x2); needs Cin*r*r == Cout and an
+                              * fp32 input; the int8 output is unaffected */
+    int32_t fuse_hidden;     /* 1 (default): run eligible runs of three hidden 3x3 layers as ONE launch (intermediates
+                              * stay in LDS); 0: one launch per layer */
+    int32_t wg_budget;       /* workgroup slots one launch may fill; 0 (default) = one full round of the chip (occupancy x CUs).
+                              * The persistent kernels cut every 64-column strip into as many vertical runs as fit the budget:
+                              * a small budget leaves compute units to a concurrent stream (and makes a workgroup walk many
+                              * tiles, which the tests use to cover the steady-state walk on small frames) */
+    float i8_in_scale;       /* 0 (default): an SESRQ_I8 input frame already is q0 (input.0.pt).  > 0: it is the int8 OUTPUT of an
+                              * upstream net in the domain (i8_in_scale, i8_in_zero) = that net's (scale_out, zero[L]); the first
+                              * layer re-quantises it while staging, x = (q - zero) * f32(scale) then clamp8(rint(x/s0 + z0)) --
+                              * bit-identical to handing the upstream net's fp32 output over (the float hand-off between chained
+                              * nets) at a quarter of the bytes */
+    int32_t i8_in_zero;
+} sesrq_options;
+void sesrq_default_options(sesrq_options *opts);
 
 /* One collapsed convolution with its integer epilogue.
  *   w         : conv.weight.K.pt   (myQL/quan_func.py:71,78)  [oc][ic][k][k] int8
@@ -76,12 +96,12 @@ typedef struct sesrq_net sesrq_net;
 /* ---- device path ------------------------------------------------------------------ */
 
 /* Validates the bundle, repacks the weights for the kernels and uploads them to the current
- * HIP device.  The net is immutable afterwards: forward calls are thread-safe and
- * stream-ordered.  Replaces quantize_model_weight's file output + every torch.load of
+ * HIP device.  The net is immutable afterwards (options included): forward calls are thread-safe
+ * and stream-ordered, on the device the net was created on (a forward issued while another device
+ * is current is refused).  Replaces quantize_model_weight's file output + every torch.load of
  * the output_pt/ tree inside the five callables. */
-int sesrq_create(const sesrq_net_desc *desc, sesrq_net **out);
+int sesrq_create(const sesrq_net_desc *desc, const sesrq_options *opts, sesrq_net **out);
 void sesrq_destroy(sesrq_net *net);
-int sesrq_set_option(sesrq_net *net, int option, int value);
 /* 1 if sesrq_create proved (exhaustively, on the device) that the 3-instruction reciprocal form of
  * the input quantiser's x / scale_in is bit-identical for this net; 0 = IEEE division is used. */
 int sesrq_fast_division_proven(const sesrq_net *net);
@@ -108,20 +128,28 @@ typedef struct sesrq_taps {
     void *act[SESRQ_MAX_LAYERS];
     void *pe_out[SESRQ_MAX_LAYERS];
     void *pe_add[SESRQ_MAX_LAYERS];
+    /* (L, 2) int32, zeroed by the call: [k][0] = number of PE sums of layer k above the PE_ACC_BIT range,
+     * [k][1] = below it, BEFORE saturation -- the events the reference reports as 'max_overflow' /
+     * 'min_overflow' (myQL/quan_func.py:358-361) and then saturates silently, as this library does. */
+    void *overflow;
 } sesrq_taps;
 int sesrq_forward_debug(const sesrq_net *net, const void *in, int in_dtype, void *out_q, void *out_f,
                         int N, int H, int W, void *workspace, size_t workspace_bytes, void *stream,
                         const sesrq_taps *taps);
 
+/* The launch sequence of sesrq_forward for this net: launch j runs layers first[j] .. first[j]+count[j]-1
+ * (count 3 = fused hidden trio).  Returns the number of launches (<= n_layers); first/count may be NULL. */
+int sesrq_launch_plan(const sesrq_net *net, int *first, int *count);
+
 /* Measurement hook: runs `iters` forwards back to back on `stream` with a HIP event pair around
- * every layer launch (events recorded on the same stream as the kernels), synchronises once at
- * the end and returns the AVERAGE device time per layer launch in layer_ms[0..L-1] (ms) and the
+ * every launch (events recorded on the same stream as the kernels), synchronises once at
+ * the end and returns the AVERAGE device time per launch in launch_ms[0..sesrq_launch_plan()-1] (ms) and the
  * average time of a whole forward in *forward_ms.  Not part of the hot path. */
 int sesrq_forward_timed(const sesrq_net *net, const void *in, int in_dtype, void *out_q, void *out_f,
                         int N, int H, int W, void *workspace, size_t workspace_bytes, void *stream,
-                        int iters, float *layer_ms, float *forward_ms);
+                        int iters, float *launch_ms, float *forward_ms);
 
-/* Name of the kernel family the net resolved to for layer k ("dot4-general", "mfma-merged", ...). */
+/* Name of the kernel the net resolved to for layer k ("dot4-general", "mfma-h3-merged", "mfma-trio-merged", ...). */
 const char *sesrq_layer_engine(const sesrq_net *net, int k);
 
 /* ---- calibration pass (the reference's exe_mode 0) ------------------------ */

@@ -155,7 +155,7 @@ def quantize_input(x: np.ndarray, s0: float, z0: int) -> np.ndarray:
     return np.clip(np.rint(np.asarray(x, F32) / F32(s0) + F32(z0)), -128, 127).astype(np.int8)
 
 
-def conv_pe(q: np.ndarray, lay: Layer, z_in: int, pe: int, acc_bits: int, add_bits: int):
+def conv_pe(q: np.ndarray, lay: Layer, z_in: int, pe: int, acc_bits: int, add_bits: int, return_raw: bool = False):
     """One layer's integer accumulate.  q: (N,IC,H,W) int8 -> (pe_out (N,pe,OC,H,W), acc (N,OC,H,W)) int64.
 
     pe_out[p] = clamp_acc( sum_{ic = p mod pe, taps} W*q )   with the image padded by zc = max(z_in,-128)
@@ -180,8 +180,11 @@ def conv_pe(q: np.ndarray, lay: Layer, z_in: int, pe: int, acc_bits: int, add_bi
             for kx in range(k):
                 patch = qp[:, ch, ky:ky + H, kx:kx + W]                # (N, c, H, W)
                 pe_out[:, p] += np.einsum("oc,nchw->nohw", w[:, ch, ky, kx], patch, optimize=True)
-    pe_out = _sat(pe_out.astype(np.int64), acc_bits)
+    pe_raw = pe_out.astype(np.int64)          # before saturation: what the reference tests for its overflow prints (:358-361)
+    pe_out = _sat(pe_raw, acc_bits)
     acc = _sat(pe_out.sum(1), add_bits) + lay.add_const.astype(np.int64)[None, :, None, None]
+    if return_raw:
+        return pe_out, acc, pe_raw
     return pe_out, acc
 
 
@@ -217,8 +220,9 @@ def forward(net: Net, x: np.ndarray, keep: bool = False) -> Dict[str, np.ndarray
     for k, lay in enumerate(net.layers):
         if keep:
             st[f"input{k}"] = q
-        pe_out, acc = conv_pe(q, lay, net.zero[k], net.pe, net.acc_bits, net.add_bits)
+        pe_out, acc, pe_raw = conv_pe(q, lay, net.zero[k], net.pe, net.acc_bits, net.add_bits, return_raw=True)
         if keep:
+            st[f"pe_raw{k}"] = pe_raw                  # all frames, int64, un-saturated
             st[f"pe_out{k}"] = pe_out[0].astype(np.int32)
             st[f"pe_add{k}"] = (acc - lay.add_const.astype(np.int64)[None, :, None, None]).astype(np.int32)
         t = requant(acc, lay.M, lay.n)

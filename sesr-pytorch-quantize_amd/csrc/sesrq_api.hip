@@ -90,9 +90,7 @@ static void pack_mfma_frags(const sesrq_layer_desc &d, int kind, bool general, b
     switch (kind) {
         case MFMA_H3: F = general ? 4 : 3; break;
         case MFMA_H5: F = general ? 8 : 7; break;
-        case MFMA_H5L: F = general ? 8 : 10; break;
         case MFMA_F5: F = general ? 8 : 2; break;
-        case MFMA_F5L: F = general ? 12 : 3; break;
         case MFMA_H5P: F = 7; break;
     }
     out.assign((size_t)16 + (size_t)F * 64 * 4, 0);
@@ -130,15 +128,7 @@ static void pack_mfma_frags(const sesrq_layer_desc &d, int kind, bool general, b
                         if (!in_l || (g == 3 && i == 0)) ky = -1;
                     }
                 }
-                else if (kind == MFMA_H5L && !general) { ky = f >> 1; kx = 4 * (f & 1) + g; ch = chmap16(b); if (kx > 4) ky = -1; }
-                else if (kind == MFMA_H5L) {
-                    const int fi = f >> 2, p = f & 3;
-                    ch = p + 4 * j;
-                    if (fi == 0) { ky = g; kx = i; }
-                    else if (g == 0) { ky = 4; kx = i; }
-                    else if (g == 1) { ky = i; kx = 4; }
-                    else if (g == 2 && i == 0) { ky = 4; kx = 4; }
-                } else if (kind == MFMA_H5P) {
+                else if (kind == MFMA_H5P) {
                     ch = chmap16(b);
                     if (f < 5) { ky = f; kx = g; }
                     else if (f == 5) { ky = g; kx = 4; }
@@ -159,13 +149,6 @@ static void pack_mfma_frags(const sesrq_layer_desc &d, int kind, bool general, b
                         const bool dup = (g == 3 && i == 0);                              // (2,4) belongs to lane group 0
                         if (!in_l || dup) ky = -1;
                     }
-                    if (general && ch != p) ky = -1;
-                } else if (kind == MFMA_F5L) {
-                    const int npe = general ? 4 : 1, fi = f / npe, p = f % npe;
-                    static const int tky[3][4] = {{0, 1, 2, 3}, {4, 0, 1, 2}, {3, 4, -1, -1}};
-                    static const int tsg[3][4] = {{0, 0, 0, 0}, {0, 1, 1, 1}, {1, 1, 0, 0}};
-                    ky = tky[fi][g]; kx = 4 * tsg[fi][g] + i; ch = j;
-                    if (kx > 4) ky = -1;
                     if (general && ch != p) ky = -1;
                 }
                 const int oc = ocmap(m);
@@ -205,9 +188,25 @@ extern "C" {
 const char *sesrq_last_error(void) { return g_err.c_str(); }
 int sesrq_version(void) { return SESRQ_VERSION; }
 
-int sesrq_create(const sesrq_net_desc *d, sesrq_net **out) {
+void sesrq_default_options(sesrq_options *o) {
+    if (!o) return;
+    o->engine = SESRQ_ENGINE_AUTO;
+    o->force_general = 0;
+    o->exact_div = 0;
+    o->anchor_add = 0;
+    o->fuse_hidden = 1;
+    o->wg_budget = 0;
+    o->i8_in_scale = 0.f;
+    o->i8_in_zero = 0;
+}
+
+int sesrq_create(const sesrq_net_desc *d, const sesrq_options *opts, sesrq_net **out) {
     if (!d || !out) { set_error("sesrq_create: null argument"); return 1; }
     *out = nullptr;
+    sesrq_options o;
+    sesrq_default_options(&o);
+    if (opts) o = *opts;
+    if (o.engine < SESRQ_ENGINE_AUTO || o.engine > SESRQ_ENGINE_MFMA) { set_error("sesrq_create: bad engine option"); return 1; }
     const int L = d->n_layers;
     if (L < 3 || L > SESRQ_MAX_LAYERS) { set_error("sesrq_create: n_layers must be in [3,16]"); return 1; }
     if (d->pe_num != 4) { set_error("sesrq_create: only pe_num == 4 is supported (define.py PE)"); return 1; }
@@ -248,6 +247,19 @@ int sesrq_create(const sesrq_net_desc *d, sesrq_net **out) {
     net->acc_bits = d->pe_acc_bits;
     net->add_bits = d->pe_add_bits;
     net->rc_separate = (d->zero[1] != -128);
+    net->engine = o.engine;
+    net->force_general = o.force_general ? 1 : 0;
+    net->force_exact_div = o.exact_div ? 1 : 0;
+    net->fuse_hidden = o.fuse_hidden ? 1 : 0;
+    if (o.wg_budget < 0) { set_error("sesrq_create: wg_budget must be >= 0"); delete net; return 1; }
+    net->wg_budget = o.wg_budget;
+    if (!(o.i8_in_scale >= 0.f) || o.i8_in_zero < -32768 || o.i8_in_zero > 127) { set_error("sesrq_create: bad int8 input domain"); delete net; return 1; }
+    net->i8_in_scale = o.i8_in_scale;
+    net->i8_in_zero = o.i8_in_zero;
+    if (o.anchor_add && d->layers[0].ic * d->pixel_shuffle * d->pixel_shuffle != d->layers[L - 1].oc) {
+        set_error("sesrq_create: anchor add needs as many output as input channels"); delete net; return 1;
+    }
+    net->anchor_add = o.anchor_add ? 1 : 0;
     if (hipGetDevice(&net->device) != hipSuccess) { set_error("sesrq_create: no HIP device"); delete net; return 1; }
     net->layers.resize(L);
     for (int k = 0; k < L; ++k) {
@@ -293,19 +305,6 @@ int sesrq_create(const sesrq_net_desc *d, sesrq_net **out) {
                     return 1;
                 }
             }
-            if (lp.mfma_kind == MFMA_F5 || (lp.mfma_kind == MFMA_H5 && k == L - 1)) {
-                for (int gen = 0; gen < 2; ++gen) {
-                    std::vector<int> fr;
-                    pack_mfma_frags(l, lp.mfma_kind == MFMA_F5 ? MFMA_F5L : MFMA_H5L, gen == 1, k == L - 1, fr);
-                    int4 **dst = gen ? &lp.d_afrag_f5l_general : &lp.d_afrag_f5l_merged;
-                    if (hipMalloc((void **)dst, fr.size() * sizeof(int)) != hipSuccess ||
-                        hipMemcpy(*dst, fr.data(), fr.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess) {
-                        set_error("sesrq_create: device upload failed");
-                        sesrq_destroy(net);
-                        return 1;
-                    }
-                }
-            }
             if (k == L - 1 && lp.mfma_kind == MFMA_H5 && l.oc <= 4) {
                 std::vector<int> fr;
                 pack_mfma_frags(l, MFMA_H5P, true, true, fr);
@@ -338,15 +337,18 @@ int sesrq_create(const sesrq_net_desc *d, sesrq_net **out) {
         const bool hyb = lp.general && __builtin_popcount(lp.risky_mask) == 1 && d->pe_acc_bits == 18 && d->pe_add_bits == 20;
         lp.engine_mfma = lp.mfma_kind == MFMA_NONE ? lp.engine_dot4 : std::string(kn[lp.mfma_kind]) + (hyb ? "-hybrid" : (lp.general ? "-general" : "-merged"));
         if (lp.d_afrag_pesplit) lp.engine_mfma = std::string("mfma-h5p-") + (lp.general ? "general" : "merged");
-        lp.engine = lp.engine_mfma;
+        lp.engine = (net->engine == SESRQ_ENGINE_DOT4) ? lp.engine_dot4 : lp.engine_mfma;
     }
+    // fused hidden trios, greedy from the residual-merging layer L-2 backwards: three consecutive 3x3 16->16 layers whose
+    // load-time proof allows the merged accumulation mode
+    net->trio_len.assign(L, 0);
+    auto trio_ok = [&](int k) {
+        const LayerPlan &lp = net->layers[k];
+        return k >= 1 && k <= L - 2 && lp.mfma_kind == MFMA_H3 && !lp.general && lp.ic == 16 && lp.oc == 16;
+    };
+    for (int k = L - 4; k >= 1 && trio_ok(k) && trio_ok(k + 1) && trio_ok(k + 2); k -= 3) net->trio_len[k] = 3;
     net->fd = prove_fastdiv(d->scale_in, d->zero[0]);
     net->layers[0].base.fd = net->fd;
-    // fused engine: reference topology 5x5 / 3x3 x3 / 5x5, standard 18/20-bit PE model, z1 == -128
-    net->fused_ok = (L == 5) && net->layers[0].mfma_kind == MFMA_F5 && net->layers[1].mfma_kind == MFMA_H3 &&
-                    net->layers[2].mfma_kind == MFMA_H3 && net->layers[3].mfma_kind == MFMA_H3 &&
-                    net->layers[4].mfma_kind == MFMA_H5 && !net->rc_separate && d->pe_acc_bits == 18 && d->pe_add_bits == 20 &&
-                    d->layers[0].relu && d->layers[1].relu && d->layers[2].relu && d->layers[3].relu && !d->layers[4].relu;
     *out = net;
     return 0;
 }
@@ -360,49 +362,35 @@ void sesrq_destroy(sesrq_net *net) {
         if (lp.d_afrag_merged) (void)hipFree(lp.d_afrag_merged);
         if (lp.d_afrag_pesplit) (void)hipFree(lp.d_afrag_pesplit);
         if (lp.d_afrag_others) (void)hipFree(lp.d_afrag_others);
-        if (lp.d_afrag_f5l_general) (void)hipFree(lp.d_afrag_f5l_general);
-        if (lp.d_afrag_f5l_merged) (void)hipFree(lp.d_afrag_f5l_merged);
     }
     delete net;
 }
 
-int sesrq_set_option(sesrq_net *net, int option, int value) {
-    if (!net) { set_error("sesrq_set_option: null net"); return 1; }
-    switch (option) {
-        case SESRQ_OPT_ENGINE:
-            if (value < SESRQ_ENGINE_AUTO || value > SESRQ_ENGINE_FUSED) { set_error("sesrq_set_option: bad engine"); return 1; }
-            if (value == SESRQ_ENGINE_FUSED && !net->fused_ok) { set_error("sesrq_set_option: this net is not eligible for the fused engine"); return 1; }
-            net->engine = value;
-            for (auto &lp : net->layers) lp.engine = (value == SESRQ_ENGINE_DOT4) ? lp.engine_dot4 : lp.engine_mfma;
-            return 0;
-        case SESRQ_OPT_FORCE_GENERAL: net->force_general = value ? 1 : 0; return 0;
-        case SESRQ_OPT_EXACT_DIV: net->force_exact_div = value ? 1 : 0; return 0;
-        case SESRQ_OPT_ANCHOR_ADD:
-            if (value && net->layers[0].ic * net->ps * net->ps != net->layers[net->L - 1].oc) {
-                set_error("sesrq_set_option: anchor add needs as many output as input channels"); return 1;
-            }
-            net->anchor_add = value ? 1 : 0; return 0;
-    }
-    set_error("sesrq_set_option: unknown option");
-    return 1;
-}
-
-static bool use_fused(const sesrq_net *net, int in_dtype, const sesrq_taps *taps) {
-    // opt-in only: correct, but slower than the per-layer MFMA kernels this round
-    return net->fused_ok && net->engine == SESRQ_ENGINE_FUSED && in_dtype == SESRQ_F32 && !taps && !net->anchor_add;
+// the fused hidden trio runs in the production forward (no debug taps), on the MFMA kernels, unless the per-PE path is forced
+static bool trio_active(const sesrq_net *net, const sesrq_taps *taps) {
+    return net->fuse_hidden && net->engine != SESRQ_ENGINE_DOT4 && !net->force_general && !taps;
 }
 
 int sesrq_fast_division_proven(const sesrq_net *net) { return net ? net->fd.ok : 0; }
 
 const char *sesrq_layer_engine(const sesrq_net *net, int k) {
     if (!net || k < 0 || k >= net->L) return "";
-    if (net->fused_ok && net->engine == SESRQ_ENGINE_FUSED) {
-        static thread_local std::string s;
-        const bool gen = net->layers[k].general || net->force_general;
-        s = std::string("fused5-") + (gen ? "general" : "merged");
-        return s.c_str();
-    }
+    for (int j = std::max(1, k - 2); j <= k; ++j)
+        if (trio_active(net, nullptr) && net->trio_len[j] == 3 && k < j + 3) return "mfma-trio-merged";
     return net->layers[k].engine.c_str();
+}
+
+int sesrq_launch_plan(const sesrq_net *net, int *first, int *count) {
+    if (!net) return 0;
+    int n = 0;
+    for (int k = 0; k < net->L;) {
+        const int c = (trio_active(net, nullptr) && net->trio_len[k] == 3) ? 3 : 1;
+        if (first) first[n] = k;
+        if (count) count[n] = c;
+        ++n;
+        k += c;
+    }
+    return n;
 }
 
 size_t sesrq_workspace_bytes(const sesrq_net *net, int N, int H, int W) {
@@ -421,58 +409,62 @@ static int forward_impl(const sesrq_net *net, const void *in, int in_dtype, void
     if ((uintptr_t)workspace & 15) { set_error("sesrq_forward: workspace must be 16-byte aligned"); return 1; }
     const WsLayout wl = ws_layout(net, N, H, W);
     if (workspace_bytes < wl.total) { set_error("sesrq_forward: workspace too small (see sesrq_workspace_bytes)"); return 1; }
+    {   // the net's device copy of the bundle lives on net->device: a launch from another current device would read foreign pointers
+        int dev = -1;
+        if (hipGetDevice(&dev) != hipSuccess || dev != net->device) {
+            set_error("sesrq_forward: the current HIP device (" + std::to_string(dev) + ") is not the device the net was created on (" +
+                      std::to_string(net->device) + ")");
+            return 1;
+        }
+    }
     hipStream_t st = (hipStream_t)stream;
     char *ws = (char *)workspace;
     const int L = net->L;
-    if (use_fused(net, in_dtype, taps)) {
-        FusedArgs f;
-        memset(&f, 0, sizeof(f));
-        f.in = in; f.out_q = out_q; f.out_f = (float *)out_f;
-        f.N = N; f.H = H; f.W = W;
-        f.ic = net->layers[0].ic; f.oc = net->layers[4].oc; f.ps = net->ps;
-        const int strips = (W + 63) / 64;
-        int nchunks = (int)((512 + (long long)strips * N / 2) / ((long long)strips * N));
-        nchunks = std::max(1, std::min(nchunks, (H + 15) / 16));
-        f.chunk = (H + nchunks - 1) / nchunks;
-        const ConvArgs &a0 = net->layers[0].base, &a4 = net->layers[4].base;
-        f.pad_in0 = a0.pad_word;
-        f.fd = net->force_exact_div ? FastDiv{0, 0.f, 0.f, 0.f} : net->fd;
-        f.s_in = a0.s_in; f.z_in = a0.z_in; f.s_out = a4.s_out; f.z_out = a4.z_out;
-        f.Mres = a0.Mres; f.shres = a0.shres; f.z_merge = a0.z_merge;
-        bool gen[5];
-        for (int k = 0; k < 5; ++k) gen[k] = net->layers[k].general || net->force_general;
-        const bool genh = gen[1] || gen[2] || gen[3];
-        for (int k = 0; k < 5; ++k) {
-            const LayerPlan &lp = net->layers[k];
-            const bool g = (k == 0) ? gen[0] : (k == 4 ? gen[4] : genh);
-            f.l[k].afrag = g ? lp.d_afrag_general : lp.d_afrag_merged;
-            if (k == 0 || k == 4) f.l[k].afrag = g ? lp.d_afrag_f5l_general : lp.d_afrag_f5l_merged;
-            f.l[k].Mf = lp.base.Mf; f.l[k].sh = lp.base.sh; f.l[k].z_next = lp.base.z_next;
-            f.l[k].pad_next = (k < 4) ? net->layers[k + 1].base.pad_word : 0;
-        }
-        if (ev && hipEventRecord(ev[0], st) != hipSuccess) { set_error("hipEventRecord failed"); return 1; }
-        if (launch_fused5(f, gen[0], genh, gen[4], st)) return 1;
-        if (ev) {
-            for (int k = 1; k < 2 * L; ++k)
-                if (hipEventRecord(ev[k], st) != hipSuccess) { set_error("hipEventRecord failed"); return 1; }
-        }
-        return 0;
+    if (taps && taps->overflow && hipMemsetAsync(taps->overflow, 0, (size_t)L * 2 * sizeof(int), st) != hipSuccess) {
+        set_error("sesrq_forward: clearing the overflow counters failed"); return 1;
     }
     // buffers: S = layer-0 output (kept for the residual), A/B ping-pong, RC optional
     void *bufS = ws + wl.off_s, *bufA = ws + wl.off_a, *bufB = ws + wl.off_b;
     void *bufRC = net->rc_separate ? (void *)(ws + wl.off_rc) : bufS;
     const void *cur = in;
-    for (int k = 0; k < L; ++k) {
+    int launch = 0;
+    for (int k = 0; k < L; ++launch) {
         const LayerPlan &lp = net->layers[k];
+        if (trio_active(net, taps) && net->trio_len[k] == 3) {
+            // ---- fused hidden trio: layers k, k+1, k+2 in one launch (sesrq_trio.hip)
+            TrioArgs t;
+            memset(&t, 0, sizeof(t));
+            void *dst = (cur == bufA) ? bufB : bufA;
+            t.in = cur; t.out = dst; t.rc_in = bufRC;
+            t.N = N; t.H = H; t.W = W;
+            t.wg_budget = net->wg_budget;
+            t.pad_in = lp.base.pad_word;
+            t.Mres = lp.base.Mres; t.shres = lp.base.shres; t.z_merge = lp.base.z_merge;
+            for (int j = 0; j < 3; ++j) {
+                const LayerPlan &lj = net->layers[k + j];
+                t.l[j].afrag = lj.d_afrag_merged;
+                t.l[j].Mf = lj.base.Mf; t.l[j].sh = lj.base.sh; t.l[j].z_next = lj.base.z_next;
+                t.l[j].zlo = lj.base.relu ? fmaxf(lj.base.z_next, -128.f) : -128.f;
+                t.l[j].pad_next = net->layers[k + j + 1].base.pad_word;
+            }
+            if (ev && hipEventRecord(ev[2 * launch], st) != hipSuccess) { set_error("hipEventRecord failed"); return 1; }
+            if (launch_trio(t, (k + 2 == L - 2) ? EPI_PRERES : EPI_MID, st)) return 1;
+            if (ev && hipEventRecord(ev[2 * launch + 1], st) != hipSuccess) { set_error("hipEventRecord failed"); return 1; }
+            cur = dst;
+            k += 3;
+            continue;
+        }
         ConvArgs a = lp.base;
-        const bool dbg = taps && (taps->pe_out[k] || taps->pe_add[k]);
+        const bool dbg = taps && (taps->pe_out[k] || taps->pe_add[k] || taps->overflow);
         LayerPlan eff = lp;
         eff.general = lp.general || net->force_general || dbg;
         a.wpk = eff.general ? lp.d_wpk_general : lp.d_wpk_merged;
         a.N = N; a.H = H; a.W = W;
+        a.wg_budget = net->wg_budget;
         if (net->force_exact_div) a.fd.ok = 0;
         a.in = cur;
-        int src = (k == 0) ? (in_dtype == SESRQ_F32 ? SRC_F32 : SRC_I8) : SRC_NHWC16;
+        int src = (k == 0) ? (in_dtype == SESRQ_F32 ? SRC_F32 : (net->i8_in_scale > 0.f ? SRC_I8D : SRC_I8)) : SRC_NHWC16;
+        a.s_prev = net->i8_in_scale; a.z_prev = (float)net->i8_in_zero;
         int epi = (k == L - 1) ? EPI_LAST : (k == L - 2 ? EPI_PRERES : EPI_MID);
         void *dst = nullptr;
         if (k == 0) { dst = bufS; a.rc_out = net->rc_separate ? bufRC : nullptr; }
@@ -481,16 +473,19 @@ static int forward_impl(const sesrq_net *net, const void *in, int in_dtype, void
         a.rc_in = bufRC;
         a.out_q = out_q; a.out_f = (float *)out_f;
         a.anchor = (net->anchor_add && in_dtype == SESRQ_F32) ? (const float *)in : nullptr;
+        // the quantised input of layer 0 (input.0.pt) is a tap of the dot4 kernel: any debug tap on layer 0 runs it there
+        const bool q0tap = taps && k == 0 && taps->act[0];
         if (taps) {
             a.dbg_pe = (int *)taps->pe_out[k];
             a.dbg_add = (int *)taps->pe_add[k];
+            a.dbg_ovf = taps->overflow ? (int *)taps->overflow + 2 * k : nullptr;
             if (k == 0) a.dbg_q0 = (signed char *)taps->act[0];
             else if (taps->act[k] && launch_unpack_nhwc16(cur, (signed char *)taps->act[k], N, lp.ic, H, W, st)) {
                 set_error("sesrq_forward: debug unpack launch failed"); return 1;
             }
         }
-        if (ev && hipEventRecord(ev[2 * k], st) != hipSuccess) { set_error("hipEventRecord failed"); return 1; }
-        const bool use_mfma = net->engine != SESRQ_ENGINE_DOT4 && lp.mfma_kind != MFMA_NONE && !dbg;
+        if (ev && hipEventRecord(ev[2 * launch], st) != hipSuccess) { set_error("hipEventRecord failed"); return 1; }
+        const bool use_mfma = net->engine != SESRQ_ENGINE_DOT4 && lp.mfma_kind != MFMA_NONE && !dbg && !q0tap;
         if (use_mfma) {
             a.afrag = eff.general ? lp.d_afrag_general : lp.d_afrag_merged;
             // exactly one PE can saturate (and nothing forces the full per-PE path): merged chain + that PE's chain
@@ -499,8 +494,9 @@ static int forward_impl(const sesrq_net *net, const void *in, int in_dtype, void
             if (lp.d_afrag_pesplit) a.afrag = lp.d_afrag_pesplit;
             if (launch_mfma(lp, a, src, epi, eff.general, st, one_pe)) return 1;
         } else if (launch_dot4(eff, a, src, epi, st)) return 1;
-        if (ev && hipEventRecord(ev[2 * k + 1], st) != hipSuccess) { set_error("hipEventRecord failed"); return 1; }
+        if (ev && hipEventRecord(ev[2 * launch + 1], st) != hipSuccess) { set_error("hipEventRecord failed"); return 1; }
         cur = dst;
+        ++k;
     }
     return 0;
 }
@@ -516,28 +512,28 @@ int sesrq_forward(const sesrq_net *net, const void *in, int in_dtype, void *out_
 }
 
 int sesrq_forward_timed(const sesrq_net *net, const void *in, int in_dtype, void *out_q, void *out_f, int N, int H, int W,
-                        void *workspace, size_t workspace_bytes, void *stream, int iters, float *layer_ms, float *forward_ms) {
-    if (!net || iters < 1 || !layer_ms) { set_error("sesrq_forward_timed: bad argument"); return 1; }
-    const int L = net->L;
-    std::vector<hipEvent_t> ev((size_t)2 * L * iters);
+                        void *workspace, size_t workspace_bytes, void *stream, int iters, float *launch_ms, float *forward_ms) {
+    if (!net || iters < 1 || !launch_ms) { set_error("sesrq_forward_timed: bad argument"); return 1; }
+    const int NL = sesrq_launch_plan(net, nullptr, nullptr);
+    std::vector<hipEvent_t> ev((size_t)2 * NL * iters);
     for (auto &e : ev) HIP_OK(hipEventCreate(&e));
     int rc = 0;
     for (int it = 0; it < iters && !rc; ++it)
         rc = forward_impl(net, in, in_dtype, out_q, out_f, N, H, W, workspace, workspace_bytes, stream, nullptr,
-                          ev.data() + (size_t)2 * L * it);
+                          ev.data() + (size_t)2 * NL * it);
     if (!rc && hipStreamSynchronize((hipStream_t)stream) != hipSuccess) { set_error("hipStreamSynchronize failed"); rc = 1; }
     if (!rc) {
-        for (int k = 0; k < L; ++k) layer_ms[k] = 0.f;
+        for (int k = 0; k < NL; ++k) launch_ms[k] = 0.f;
         double fw = 0;
         for (int it = 0; it < iters; ++it) {
-            hipEvent_t *e = ev.data() + (size_t)2 * L * it;
-            for (int k = 0; k < L; ++k) {
+            hipEvent_t *e = ev.data() + (size_t)2 * NL * it;
+            for (int k = 0; k < NL; ++k) {
                 float ms = 0.f;
                 (void)hipEventElapsedTime(&ms, e[2 * k], e[2 * k + 1]);
-                layer_ms[k] += ms / iters;
+                launch_ms[k] += ms / iters;
             }
             float ms = 0.f;
-            (void)hipEventElapsedTime(&ms, e[0], e[2 * L - 1]);
+            (void)hipEventElapsedTime(&ms, e[0], e[2 * NL - 1]);
             fw += ms;
         }
         if (forward_ms) *forward_ms = (float)(fw / iters);

@@ -10,8 +10,8 @@
 namespace sesrq {
 
 enum Epi { EPI_MID = 0, EPI_PRERES = 1, EPI_LAST = 2 };
-enum Src { SRC_NHWC16 = 0, SRC_F32 = 1, SRC_I8 = 2 };
-enum MfmaKind { MFMA_NONE = 0, MFMA_H3 = 1, MFMA_H5 = 2, MFMA_F5 = 3, MFMA_H5P = 4, MFMA_F5L = 5, MFMA_H5L = 6 };   // F5L / H5L: first/last-layer images in the fused engine's layout
+enum Src { SRC_NHWC16 = 0, SRC_F32 = 1, SRC_I8 = 2, SRC_I8D = 3 };   // I8D: int8 frame in an upstream net's output domain
+enum MfmaKind { MFMA_NONE = 0, MFMA_H3 = 1, MFMA_H5 = 2, MFMA_F5 = 3, MFMA_H5P = 4 };
 
 // Verified fast division of the input quantiser (sesrq_verify.hip): q0(x) with x pre-clamped to
 // [xlo, xhi] and x/s formed as fma(fma(-s, x*r, x), r, x*r); ok == 1 only after an exhaustive proof.
@@ -36,9 +36,11 @@ struct ConvArgs {
     int risky_pe;
     int *dbg_pe;             // (N,4,OC,H,W) int32 or NULL
     int *dbg_add;            // (N,OC,H,W) int32 or NULL
-    signed char *dbg_q0;     // (N,IC,H,W) int8: quantised input of layer 0 or NULL
+    signed char *dbg_q0;     // (N,IC,H,W) int8: quantised input of layer 0 or NULL (dot4 kernels only)
+    int *dbg_ovf;            // [2] counters: PE sums above / below the accumulator range before saturation, or NULL (dot4 general kernels only)
     int N, H, W;
     int chunk_tiles;         // mfma engine: vertically adjacent tiles walked by one workgroup
+    int wg_budget;           // mfma engine: workgroup slots the launch may fill (0 = one round of the chip)
     int ic, oc;              // real channel counts
     int pad_word;            // zc replicated into 4 bytes
     int acc_lo, acc_hi, add_lo, add_hi;
@@ -47,6 +49,7 @@ struct ConvArgs {
     float Mres, shres;       // EPI_PRERES
     float z_merge;           // EPI_PRERES: zero of the last conv's input domain
     float s_in, z_in;        // SRC_F32: f32(scale_0), (float)zero_0
+    float s_prev, z_prev;    // SRC_I8D: the upstream net's f32(scale_L), (float)zero_L: x = (q - z_prev) * s_prev, then the input quantiser
     FastDiv fd;              // SRC_F32: proven fast form of x / s_in (fd.ok == 0 -> IEEE division)
     float s_out, z_out;      // EPI_LAST: f32(scale_L), (float) zero_L
     int relu;
@@ -54,21 +57,23 @@ struct ConvArgs {
     int add_const[SESRQ_MAX_CH];
 };
 
-// fused engine (sesrq_fused.hip): all five layers of the reference topology in one launch
-struct FusedLayer {
-    const int4 *afrag;       // same A-fragment image as the per-layer MFMA kernels
+// fused hidden trio (sesrq_trio.hip): three consecutive 3x3 16->16 merged layers in one launch
+struct TrioLayer {
+    const int4 *afrag;       // merged A-fragment image of the layer (same as the per-layer MFMA kernel's)
     float Mf, sh, z_next;
+    float zlo;               // lower clamp of the layer's output: relu ? max(z_next, -128) : -128
     int pad_next;            // pad word (zc bytes) of the NEXT layer's input
 };
-struct FusedArgs {
-    const void *in;
-    void *out_q;
-    float *out_f;
-    int N, H, W, ic, oc, ps, chunk;
-    int pad_in0;
-    float s_in, z_in, s_out, z_out, Mres, shres, z_merge;
-    FastDiv fd;
-    FusedLayer l[5];
+struct TrioArgs {
+    const void *in;          // NHWC16 input of the first layer
+    void *out;               // NHWC16 output of the third layer
+    const void *rc_in;       // EPI_PRERES: residual operand tensor
+    int N, H, W;
+    int chunk_steps;         // vertically adjacent 8-row steps walked by one workgroup
+    int wg_budget;           // workgroup slots the launch may fill (0 = one round of the chip)
+    int pad_in;              // pad word of the first layer's input
+    float Mres, shres, z_merge;
+    TrioLayer l[3];
 };
 
 struct LayerPlan {
@@ -82,7 +87,6 @@ struct LayerPlan {
     int4 *d_afrag_merged = nullptr;  // device
     int4 *d_afrag_pesplit = nullptr; // device: last layer with OC <= 4 (MFMA_H5P image), else NULL
     int4 *d_afrag_others = nullptr;  // device: exactly one risky PE: merged image with that PE's channels zeroed, else NULL
-    int4 *d_afrag_f5l_general = nullptr, *d_afrag_f5l_merged = nullptr;   // device: MFMA_F5L / MFMA_H5L images (fused engine)
     std::string engine_dot4, engine_mfma;
     ConvArgs base;           // constant fields prefilled
     // static saturation analysis (per layer)
@@ -96,7 +100,7 @@ void set_error(const std::string &msg);
 int launch_dot4(const LayerPlan &lp, const ConvArgs &a, int src, int epi, hipStream_t st);
 // mfma engine
 int launch_mfma(const LayerPlan &lp, const ConvArgs &a, int src, int epi, bool general, hipStream_t st, bool one_risky_pe = false);
-int launch_fused5(const FusedArgs &a, bool gen0, bool genh, bool gen4, hipStream_t st);
+int launch_trio(const TrioArgs &a, int epi_c, hipStream_t st);
 int launch_unpack_nhwc16(const void *nhwc, signed char *nchw, int N, int C, int H, int W, hipStream_t st);
 
 }  // namespace sesrq
@@ -109,12 +113,16 @@ struct sesrq_net {
     uint32_t M_res = 0, n_res = 0;
     int ps = 1;
     int acc_bits = 18, add_bits = 20;
-    int engine = SESRQ_ENGINE_AUTO;
+    int engine = SESRQ_ENGINE_AUTO;     // options are fixed at sesrq_create: the net is immutable afterwards
     int force_general = 0;
     int force_exact_div = 0;
     int anchor_add = 0;
+    int fuse_hidden = 1;
+    int wg_budget = 0;
+    float i8_in_scale = 0.f;            // > 0: int8 input frames are in this (scale, zero) domain of an upstream net
+    int i8_in_zero = 0;
+    std::vector<int> trio_len;          // trio_len[k] == 3: layers k..k+2 are eligible for the fused hidden trio
     int device = 0;
     bool rc_separate = false;   // zero[1] != -128 -> layer 0 writes its own rc tensor
     sesrq::FastDiv fd = {0, 0.f, 0.f, 0.f};
-    bool fused_ok = false;      // topology/parameters eligible for the fused engine
 };

@@ -65,6 +65,9 @@ __global__ __launch_bounds__(256) void conv_dot4_kernel(const ConvArgs a) {
                     if constexpr (SRC == SRC_F32) {
                         const float xv = reinterpret_cast<const float *>(a.in)[off];
                         q = (int)q8f(__fadd_rn(__fdiv_rn(xv, a.s_in), a.z_in));
+                    } else if constexpr (SRC == SRC_I8D) {
+                        const float xv = __fmul_rn((float)(int)reinterpret_cast<const signed char *>(a.in)[off] - a.z_prev, a.s_prev);
+                        q = (int)q8f(__fadd_rn(__fdiv_rn(xv, a.s_in), a.z_in));
                     } else {
                         q = reinterpret_cast<const signed char *>(a.in)[off];
                     }
@@ -125,6 +128,7 @@ __global__ __launch_bounds__(256) void conv_dot4_kernel(const ConvArgs a) {
 
     // ---- epilogue
     float t[OCP];
+    int n_hi = 0, n_lo = 0;
 #pragma unroll
     for (int o = 0; o < OCP; ++o) {
         int s;
@@ -132,6 +136,10 @@ __global__ __launch_bounds__(256) void conv_dot4_kernel(const ConvArgs a) {
             int pe[4];
 #pragma unroll
             for (int p = 0; p < 4; ++p) pe[p] = clampi(acc[p][o], a.acc_lo, a.acc_hi);
+            if (a.dbg_ovf && o < a.oc) {       // the reference's 'max_overflow' / 'min_overflow' events (myQL/quan_func.py:358-361)
+#pragma unroll
+                for (int p = 0; p < 4; ++p) { n_hi += acc[p][o] > a.acc_hi; n_lo += acc[p][o] < a.acc_lo; }
+            }
             s = clampi(pe[0] + pe[1] + pe[2] + pe[3], a.add_lo, a.add_hi);
             if (a.dbg_pe && o < a.oc) {
 #pragma unroll
@@ -146,6 +154,13 @@ __global__ __launch_bounds__(256) void conv_dot4_kernel(const ConvArgs a) {
         float v = __fmul_rn((float)s, a.Mf) * a.sh;
         if (a.relu) v = fmaxf(v, 0.f);
         t[o] = v;
+    }
+
+    if constexpr (GENERAL) {
+        if (a.dbg_ovf) {
+            if (n_hi) atomicAdd(a.dbg_ovf, n_hi);
+            if (n_lo) atomicAdd(a.dbg_ovf + 1, n_lo);
+        }
     }
 
     if constexpr (EPI == EPI_MID || EPI == EPI_PRERES) {
@@ -227,6 +242,7 @@ static int dispatch(const LayerPlan &lp, const ConvArgs &a, int src, int epi, hi
     if (src != SRC_NHWC16) {
         if (epi != EPI_MID) { set_error("dot4: first layer must be a hidden layer"); return 1; }
         if (src == SRC_F32) launch_one<K, 1, GENERAL, EPI_MID, 16, SRC_F32>(a, st);
+        else if (src == SRC_I8D) launch_one<K, 1, GENERAL, EPI_MID, 16, SRC_I8D>(a, st);
         else launch_one<K, 1, GENERAL, EPI_MID, 16, SRC_I8>(a, st);
         return 0;
     }

@@ -41,40 +41,6 @@ namespace sesrq {
 constexpr int MTW = 64;   // tile width : 4 waves x 16 pixels
 constexpr int MTH = 8;    // tile height: rows walked by every wave (multiple of 4); 8 beats 12 and 16 on 1080p (latency hiding vs halo)
 
-// hidden layer: q = clamp8(rint(relu(t) + z_next))            (myQL/quan_func.py:280)
-template <bool BIASED>
-__device__ __forceinline__ unsigned epi_mid(const int s[4], const ConvArgs &a, float zlo) {
-    v2f v01, v23;
-    requant4<BIASED>(s, a.Mf, a.sh, a.z_next, v01, v23);
-    return round_pack(v01, v23, zlo, 127.f);
-}
-// layer-0 residual operand rc = clamp8(rint(relu(t) - 128))    (myQL/quan_func.py:250)
-template <bool BIASED>
-__device__ __forceinline__ unsigned epi_rc(const int s[4], const ConvArgs &a) {
-    v2f v01, v23;
-    requant4<BIASED>(s, a.Mf, a.sh, -128.f, v01, v23);
-    return round_pack(v01, v23, -128.f, 127.f);
-}
-// layer L-2: long residual merged in the integer domain        (myQL/quan_func.py:249-270)
-template <bool BIASED>
-__device__ __forceinline__ unsigned epi_preres(const int s[4], unsigned rcword, const ConvArgs &a) {
-    v2f v01, v23;
-    requant4<BIASED>(s, a.Mf, a.sh, -128.f, v01, v23);
-    const unsigned rcx = rcword ^ 0x80808080u;                 // rc + 128 as unsigned bytes
-    // ic = rint(clamp(t - 128)) ; u = rc + ic + 256 = (rc + 128) + (ic + 128), an integer in [0, 510].
-    // Adding 1.5*2^23 + 128 rounds to nearest even and leaves ic + 128 in the low mantissa bits; a plain integer add of the
-    // rc byte then gives the bit pattern of the float 1.5*2^23 + u, which is exactly what the cvt-free requant
-    // (requant4<true>) takes as its input: no v_rndne, no byte->float converts, no float adds.
-    const v2f mg128 = {MAGIC + 128.f, MAGIC + 128.f};
-    v2f c01 = {med3(v01[0], -128.f, 127.f), med3(v01[1], -128.f, 127.f)}, c23 = {med3(v23[0], -128.f, 127.f), med3(v23[1], -128.f, 127.f)};
-    c01 = c01 + mg128; c23 = c23 + mg128;
-    const int u[4] = {(int)(fbits(c01[0]) + (rcx & 0xffu)), (int)(fbits(c01[1]) + ((rcx >> 8) & 0xffu)),
-                      (int)(fbits(c23[0]) + ((rcx >> 16) & 0xffu)), (int)(fbits(c23[1]) + (rcx >> 24))};
-    v2f w01, w23;
-    requant4<true>(u, a.Mres, a.shres, a.z_merge, w01, w23);
-    return round_pack(w01, w23, -128.f, 127.f);
-}
-
 // last layer: requantise into the output domain + PixelShuffle(r) store (int8 and/or fp32).
 // A lane owns output slots o = 4g..4g+3 of pixel (gy, gx); everything that depends only on the lane
 // (channel / sub-pixel decode, column offset, validity) is worked out once per kernel, a row adds one
@@ -173,42 +139,6 @@ __device__ __forceinline__ void finish_sums(int s[4], const v4i *acc, const int4
             s[i] = clampi3(t, a.add_lo, a.add_hi) + acv[i];
         }
     }
-}
-
-// 4x4 transpose between lane groups (16 lanes each) and registers; its own inverse.
-// in : w[r] in lane (n, g) = word g of row r        out: w[g'] in lane (n, r') = word g' of row r'
-__device__ __forceinline__ void transpose4(unsigned w[4]) {
-    v2u t;
-    t = __builtin_amdgcn_permlane32_swap(w[0], w[2], false, false); w[0] = t[0]; w[2] = t[1];
-    t = __builtin_amdgcn_permlane32_swap(w[1], w[3], false, false); w[1] = t[0]; w[3] = t[1];
-    t = __builtin_amdgcn_permlane16_swap(w[0], w[1], false, false); w[0] = t[0]; w[1] = t[1];
-    t = __builtin_amdgcn_permlane16_swap(w[2], w[3], false, false); w[2] = t[0]; w[3] = t[1];
-}
-
-// Per-image NHWC16 tensor addressed through a buffer descriptor: rows/pixels outside the
-// frame are dropped (stores) or read as zero (loads) by the hardware range check.
-struct RowIO {
-    __amdgpu_buffer_rsrc_t out, rc_in, rc_out;
-    int voff;        // lane (n, r' = g): byte offset of pixel (y0 + g, gx) or out-of-range
-    int row_bytes;   // W * 16
-};
-__device__ __forceinline__ RowIO make_rowio(const ConvArgs &a, int n_img, int y0, int gx, int g) {
-    RowIO io;
-    const size_t img = (size_t)a.H * a.W * 16;
-    const int bytes = (int)img;
-    io.out = __builtin_amdgcn_make_buffer_rsrc((char *)a.out + (size_t)n_img * img, 0, bytes, 0x00020000);
-    io.rc_in = __builtin_amdgcn_make_buffer_rsrc((char *)a.rc_in + (size_t)n_img * img, 0, bytes, 0x00020000);
-    io.rc_out = __builtin_amdgcn_make_buffer_rsrc((char *)a.rc_out + (size_t)n_img * img, 0, bytes, 0x00020000);
-    io.row_bytes = a.W * 16;
-    io.voff = (gx < a.W) ? ((y0 + g) * a.W + gx) * 16 : (int)0x80000000;
-    return io;
-}
-__device__ __forceinline__ void store_rows4(__amdgpu_buffer_rsrc_t rs, const RowIO &io, int y4, unsigned w[4]) {
-    transpose4(w);
-    const v4u v = {w[0], w[1], w[2], w[3]};
-    // aux 16 = sc1: the activation tensor is only read again by the NEXT kernel; measured against the default policy,
-    // sc0|sc1 and nt on 1080p: sc1 -6 % on the first layer, -3..5 % on the hidden layers when frames overlap; nt +12 %
-    __builtin_amdgcn_raw_buffer_store_b128(v, rs, io.voff, y4 * io.row_bytes, 16);
 }
 
 // Staging of a (SH x SW) window of NHWC16 pixels, split in two phases so that a persistent
@@ -322,29 +252,6 @@ struct StageNHWC16 {
             STAMP(5 + 3 * (t - t_begin))                                                            \
         }                                                                                           \
     }
-
-// hidden-layer output of 4 rows: s4[r][i] -> requant -> transpose -> one 16-byte store per lane
-template <int EPI, bool RC, bool BIASED>
-__device__ __forceinline__ void emit_rows4(const int s4[4][4], const ConvArgs &a, const RowIO &io, int y4, float zlo) {
-    unsigned w[4];
-    if constexpr (EPI == EPI_PRERES) {
-        const v4u rv = __builtin_amdgcn_raw_buffer_load_b128(io.rc_in, io.voff, y4 * io.row_bytes, 0);
-        unsigned rcw[4] = {rv[0], rv[1], rv[2], rv[3]};
-        transpose4(rcw);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) w[r] = epi_preres<BIASED>(s4[r], rcw[r], a);
-    } else {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) w[r] = epi_mid<BIASED>(s4[r], a, zlo);
-    }
-    store_rows4(io.out, io, y4, w);
-    if constexpr (RC) {
-        unsigned rw[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) rw[r] = epi_rc<BIASED>(s4[r], a);
-        store_rows4(io.rc_out, io, y4, rw);
-    }
-}
 
 // ------------------------------------------------------------------ hidden 3x3, 16 -> 16 channels
 template <int MODE, int EPI>
@@ -678,6 +585,8 @@ struct StageFrame {
             for (int c = 0; c < 4; ++c) {
                 if constexpr (SRC == SRC_F32)
                     b[c] = quantize_in_bits(__builtin_bit_cast(float, raw[it][c]), a.s_in, a.z_in, a.fd);
+                else if constexpr (SRC == SRC_I8D)      // upstream net's int8 output: its float value, then this net's input quantiser
+                    b[c] = quantize_in_bits(__fmul_rn((float)(int)raw[it][c] - a.z_prev, a.s_prev), a.s_in, a.z_in, a.fd);
                 else
                     b[c] = raw[it][c];
                 if (c >= a.ic) b[c] = 0;
@@ -689,19 +598,16 @@ struct StageFrame {
     }
 };
 
-// 4 waves per SIMD: with the default heuristics hipcc takes 141-153 VGPRs here (3 waves); told to fit 128 it does so
-// without spilling and the extra wave hides more of the staging/quantisation latency (first layer -5 %)
+constexpr int F5_SH = MTH + 4;
+constexpr int F5_SWP = MTW + 8;         // staged pixel columns (2 halo + 64 + 2 halo + over-read)
+constexpr int F5_PITCH = F5_SWP + 8;    // LDS row pitch in pixels: 16 dwords mod 32, so the four lane groups of an
+                                        // operand read (rows g, g+1, ...) hit disjoint banks
 template <int MODE, int SRC, bool RC>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void mfma_f5_kernel(const ConvArgs a) {
+__device__ __forceinline__ void mfma_f5_body(const ConvArgs &a, int4 *buf0, int4 *buf1) {
     constexpr bool GENERAL = MODE == GEN_STD || MODE == GEN_ANY;
-    constexpr int SH = MTH + 4;
-    constexpr int SWP = MTW + 8;         // staged pixel columns (2 halo + 64 + 2 halo + over-read)
-    constexpr int PITCH = SWP + 8;       // LDS row pitch in pixels: 16 dwords mod 32, so the four lane groups of an
-                                         // operand read (rows g, g+1, ...) hit disjoint banks
-    __shared__ int4 buf0[SH * PITCH / 4], buf1[SH * PITCH / 4];      // SH rows of 4-byte pixels
+    constexpr int SH = F5_SH, SWP = F5_SWP, PITCH = F5_PITCH;
     const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, n = l & 15, g = l >> 4;
     const int x0 = blockIdx.x * MTW, n_img = blockIdx.z;
-    const size_t HW = (size_t)a.H * a.W;
     const int4 *fr = a.afrag;
     constexpr bool BIASED = MODE != GEN_ANY;     // requant without v_cvt: sums carry + MAGIC_I (needs |s| < 2^22)
     int4 ac = fr[g];
@@ -757,11 +663,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void m
                     }
                 }
                 finish_sums<MODE>(s4[r], acc, ac, a);
-                if (a.dbg_q0 && g == 0 && y0 + y < a.H && gx < a.W) {
-                    const int word = cpw[(y + 2) * PITCH + 16 * w + n + 2];
-                    for (int c = 0; c < a.ic; ++c)
-                        a.dbg_q0[((size_t)n_img * a.ic + c) * HW + (size_t)(y0 + y) * a.W + gx] = (signed char)((word >> (8 * c)) & 0xff);
-                }
             }
             emit_rows4<EPI_MID, RC, BIASED>(s4, a, io, y4, zlo);
         }
@@ -770,6 +671,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void m
     using Stage = StageFrame<SRC, SH, SWP, PITCH>;
     SESRQ_TILE_WALK(Stage, buf0, buf1, SESRQ_COMPUTE)
 #undef SESRQ_COMPUTE
+}
+// 4 waves per SIMD for the merged / hybrid first layer: with the default heuristics hipcc takes 141-153 VGPRs here (3 waves);
+// told to fit 128 it does so without spilling and the extra wave hides more of the staging/quantisation latency (-5 %).
+// NOT for the per-PE (general) variants: squeezed to 128 VGPRs, hipcc 7.2 produced a GEN_STD + residual-tensor instance whose
+// first output word was garbage in lanes 28..31 (caught by the satw_zeros golden vectors; the same source without the
+// attribute, or with unrelated extra code in the loop, is correct) -- those take the registers they ask for.
+template <int MODE, int SRC, bool RC>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void mfma_f5_kernel_w4(const ConvArgs a) {
+    __shared__ int4 buf0[F5_SH * F5_PITCH / 4], buf1[F5_SH * F5_PITCH / 4];      // SH rows of 4-byte pixels
+    mfma_f5_body<MODE, SRC, RC>(a, buf0, buf1);
+}
+template <int MODE, int SRC, bool RC>
+__global__ __launch_bounds__(256) void mfma_f5_kernel(const ConvArgs a) {
+    __shared__ int4 buf0[F5_SH * F5_PITCH / 4], buf1[F5_SH * F5_PITCH / 4];
+    mfma_f5_body<MODE, SRC, RC>(a, buf0, buf1);
 }
 
 #ifdef SESRQ_STAMPS
@@ -805,7 +721,7 @@ static void launch(K kern, ConvArgs a, hipStream_t st) {
         blocks_per_cu = it->second;
     }
     const int strips = (a.W + MTW - 1) / MTW, row_tiles = (a.H + MTH - 1) / MTH;
-    long long k = ((long long)blocks_per_cu * num_cu) / ((long long)strips * a.N);
+    long long k = (a.wg_budget > 0 ? (long long)a.wg_budget : (long long)blocks_per_cu * num_cu) / ((long long)strips * a.N);
     k = std::max(1LL, std::min<long long>(k, row_tiles));
     a.chunk_tiles = (int)((row_tiles + k - 1) / k);
     dim3 grid(strips, (row_tiles + a.chunk_tiles - 1) / a.chunk_tiles, a.N);
@@ -847,8 +763,17 @@ int launch_mfma(const LayerPlan &lp, const ConvArgs &a_in, int src, int epi, boo
             else SESRQ_BY_MODE(mfma_h5_kernel, EPI_LAST);
             break;
         case MFMA_F5:
-            if (src == SRC_F32) { if (a.rc_out) SESRQ_BY_MODE(mfma_f5_kernel, SRC_F32, true); else SESRQ_BY_MODE(mfma_f5_kernel, SRC_F32, false); }
-            else { if (a.rc_out) SESRQ_BY_MODE(mfma_f5_kernel, SRC_I8, true); else SESRQ_BY_MODE(mfma_f5_kernel, SRC_I8, false); }
+#define SESRQ_F5(...)                                                                    \
+    do {                                                                                 \
+        if (mode == MERGED) launch(mfma_f5_kernel_w4<MERGED, __VA_ARGS__>, a, st);       \
+        else if (mode == HYB) launch(mfma_f5_kernel_w4<HYB, __VA_ARGS__>, a, st);        \
+        else if (mode == GEN_STD) launch(mfma_f5_kernel<GEN_STD, __VA_ARGS__>, a, st);   \
+        else launch(mfma_f5_kernel<GEN_ANY, __VA_ARGS__>, a, st);                        \
+    } while (0)
+            if (src == SRC_F32) { if (a.rc_out) SESRQ_F5(SRC_F32, true); else SESRQ_F5(SRC_F32, false); }
+            else if (src == SRC_I8D) { if (a.rc_out) SESRQ_F5(SRC_I8D, true); else SESRQ_F5(SRC_I8D, false); }
+            else { if (a.rc_out) SESRQ_F5(SRC_I8, true); else SESRQ_F5(SRC_I8, false); }
+#undef SESRQ_F5
             break;
         default: set_error("mfma: layer shape not supported by the MFMA engine"); return 1;
     }

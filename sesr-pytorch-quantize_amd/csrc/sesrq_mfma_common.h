@@ -1,4 +1,4 @@
-// Device helpers shared by the MFMA engines (per-layer: sesrq_mfma.hip, fused: sesrq_fused.hip).
+// Device helpers shared by the MFMA kernels (per-layer: sesrq_mfma.hip, fused hidden trio: sesrq_trio.hip).
 #pragma once
 #include "sesrq_common.h"
 
@@ -103,6 +103,101 @@ __device__ __forceinline__ unsigned round_pack(v2f v01, v2f v23, float lo, float
     v2f c01 = {med3(v01[0], lo, hi), med3(v01[1], lo, hi)}, c23 = {med3(v23[0], lo, hi), med3(v23[1], lo, hi)};
     c01 = c01 + mg; c23 = c23 + mg;
     return pack_lo_bytes(fbits(c01[0]), fbits(c01[1]), fbits(c23[0]), fbits(c23[1]));
+}
+
+// ---- epilogues (AT = any struct with the ConvArgs field names Mf, sh, z_next, Mres, shres, z_merge) ----
+
+// hidden layer: q = clamp8(rint(relu(t) + z_next))            (myQL/quan_func.py:280)
+template <bool BIASED, class AT>
+__device__ __forceinline__ unsigned epi_mid(const int s[4], const AT &a, float zlo) {
+    v2f v01, v23;
+    requant4<BIASED>(s, a.Mf, a.sh, a.z_next, v01, v23);
+    return round_pack(v01, v23, zlo, 127.f);
+}
+// layer-0 residual operand rc = clamp8(rint(relu(t) - 128))    (myQL/quan_func.py:250)
+template <bool BIASED, class AT>
+__device__ __forceinline__ unsigned epi_rc(const int s[4], const AT &a) {
+    v2f v01, v23;
+    requant4<BIASED>(s, a.Mf, a.sh, -128.f, v01, v23);
+    return round_pack(v01, v23, -128.f, 127.f);
+}
+// layer L-2: long residual merged in the integer domain        (myQL/quan_func.py:249-270)
+template <bool BIASED, class AT>
+__device__ __forceinline__ unsigned epi_preres(const int s[4], unsigned rcword, const AT &a) {
+    v2f v01, v23;
+    requant4<BIASED>(s, a.Mf, a.sh, -128.f, v01, v23);
+    const unsigned rcx = rcword ^ 0x80808080u;                 // rc + 128 as unsigned bytes
+    // ic = rint(clamp(t - 128)) ; u = rc + ic + 256 = (rc + 128) + (ic + 128), an integer in [0, 510].
+    // Adding 1.5*2^23 + 128 rounds to nearest even and leaves ic + 128 in the low mantissa bits; a plain integer add of the
+    // rc byte then gives the bit pattern of the float 1.5*2^23 + u, which is exactly what the cvt-free requant
+    // (requant4<true>) takes as its input: no v_rndne, no byte->float converts, no float adds.
+    const v2f mg128 = {MAGIC + 128.f, MAGIC + 128.f};
+    v2f c01 = {med3(v01[0], -128.f, 127.f), med3(v01[1], -128.f, 127.f)}, c23 = {med3(v23[0], -128.f, 127.f), med3(v23[1], -128.f, 127.f)};
+    c01 = c01 + mg128; c23 = c23 + mg128;
+    const int u[4] = {(int)(fbits(c01[0]) + (rcx & 0xffu)), (int)(fbits(c01[1]) + ((rcx >> 8) & 0xffu)),
+                      (int)(fbits(c23[0]) + ((rcx >> 16) & 0xffu)), (int)(fbits(c23[1]) + (rcx >> 24))};
+    v2f w01, w23;
+    requant4<true>(u, a.Mres, a.shres, a.z_merge, w01, w23);
+    return round_pack(w01, w23, -128.f, 127.f);
+}
+
+// 4x4 transpose between lane groups (16 lanes each) and registers; its own inverse.
+// in : w[r] in lane (n, g) = word g of row r        out: w[g'] in lane (n, r') = word g' of row r'
+__device__ __forceinline__ void transpose4(unsigned w[4]) {
+    v2u t;
+    t = __builtin_amdgcn_permlane32_swap(w[0], w[2], false, false); w[0] = t[0]; w[2] = t[1];
+    t = __builtin_amdgcn_permlane32_swap(w[1], w[3], false, false); w[1] = t[0]; w[3] = t[1];
+    t = __builtin_amdgcn_permlane16_swap(w[0], w[1], false, false); w[0] = t[0]; w[1] = t[1];
+    t = __builtin_amdgcn_permlane16_swap(w[2], w[3], false, false); w[2] = t[0]; w[3] = t[1];
+}
+
+// Per-image NHWC16 tensor addressed through a buffer descriptor: rows/pixels outside the
+// frame are dropped (stores) or read as zero (loads) by the hardware range check.
+struct RowIO {
+    __amdgpu_buffer_rsrc_t out, rc_in, rc_out;
+    int voff;        // lane (n, r' = g): byte offset of pixel (y0 + g, gx) or out-of-range
+    int row_bytes;   // W * 16
+};
+__device__ __forceinline__ RowIO make_rowio(const ConvArgs &a, int n_img, int y0, int gx, int g) {
+    RowIO io;
+    const size_t img = (size_t)a.H * a.W * 16;
+    const int bytes = (int)img;
+    io.out = __builtin_amdgcn_make_buffer_rsrc((char *)a.out + (size_t)n_img * img, 0, bytes, 0x00020000);
+    io.rc_in = __builtin_amdgcn_make_buffer_rsrc((char *)a.rc_in + (size_t)n_img * img, 0, bytes, 0x00020000);
+    io.rc_out = __builtin_amdgcn_make_buffer_rsrc((char *)a.rc_out + (size_t)n_img * img, 0, bytes, 0x00020000);
+    io.row_bytes = a.W * 16;
+    io.voff = (gx < a.W) ? ((y0 + g) * a.W + gx) * 16 : (int)0x80000000;
+    return io;
+}
+__device__ __forceinline__ void store_rows4(__amdgpu_buffer_rsrc_t rs, const RowIO &io, int y4, unsigned w[4]) {
+    transpose4(w);
+    const v4u v = {w[0], w[1], w[2], w[3]};
+    // aux 16 = sc1: the activation tensor is only read again by the NEXT kernel; measured against the default policy,
+    // sc0|sc1 and nt on 1080p: sc1 -6 % on the first layer, -3..5 % on the hidden layers when frames overlap; nt +12 %
+    __builtin_amdgcn_raw_buffer_store_b128(v, rs, io.voff, y4 * io.row_bytes, 16);
+}
+
+// hidden-layer output of 4 rows: s4[r][i] -> requant -> transpose -> one 16-byte store per lane
+template <int EPI, bool RC, bool BIASED, class AT>
+__device__ __forceinline__ void emit_rows4(const int s4[4][4], const AT &a, const RowIO &io, int y4, float zlo) {
+    unsigned w[4];
+    if constexpr (EPI == EPI_PRERES) {
+        const v4u rv = __builtin_amdgcn_raw_buffer_load_b128(io.rc_in, io.voff, y4 * io.row_bytes, 0);
+        unsigned rcw[4] = {rv[0], rv[1], rv[2], rv[3]};
+        transpose4(rcw);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) w[r] = epi_preres<BIASED>(s4[r], rcw[r], a);
+    } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) w[r] = epi_mid<BIASED>(s4[r], a, zlo);
+    }
+    store_rows4(io.out, io, y4, w);
+    if constexpr (RC) {
+        unsigned rw[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) rw[r] = epi_rc<BIASED>(s4[r], a);
+        store_rows4(io.rc_out, io, y4, rw);
+    }
 }
 
 }  // namespace sesrq

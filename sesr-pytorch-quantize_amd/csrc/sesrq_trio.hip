@@ -1,0 +1,254 @@
+// sesrq fused hidden trio: three consecutive 3x3 16->16 layers (the reference's conv 1..3, the last one with
+// the long-residual merge, myQL/quan_func.py:244-280) in ONE launch.  The two intermediate activation tensors
+// never leave the CU: 2 x 66 MB of HBM traffic per 1080p frame and two synchronised kernel starts less than the
+// per-layer kernels (sesrq_mfma.hip), and no global staging / transpose / 16-byte store work for the two inner
+// layers (their MFMA results go to LDS as they come out: lane (n, g) owns word g of pixel n).
+//
+// Geometry: a workgroup (4 waves = 4 groups of 16 columns) owns a strip of TW = 64 COMPUTED columns of which
+// TV = 60 are valid outputs (a 3x3 layer eats one column per side; the two outermost computed columns of the
+// inner layers are never read by a valid output) and walks down it in steps of TH = 8 rows.  Three LDS
+// windows of TH + 2 rows each (IN, A, B; row pitch 66 pixels: columns -1 .. 64) hold
+//      IN: input rows  Y+1 .. Y+10        A: layer-a rows Y .. Y+9        B: layer-b rows Y-1 .. Y+8
+// while the step produces output rows Y .. Y+7: every layer lags the one before by one row, so all three
+// phases have the same access pattern (window position 2+i from positions i .. i+2) and NO row is computed
+// twice inside a chunk; between steps the last two rows of each window move to its top (132 pixels each).
+// A chunk starts cold with a partial step (4 rows of layer a, 2 rows of layer b, nothing stored).
+// Pixels outside the frame are the NEXT layer's pad value zc = max(zero, -128), exactly as the per-layer
+// kernels pad (myQL/quan_func.py:351-356): the inner epilogues select the pad word there.
+// Only the merged accumulation mode (load-time proof: no 18-/20-bit clamp can fire) is fused; anything else
+// runs on the per-layer kernels.
+#include <algorithm>
+#include <map>
+#include <mutex>
+
+#include "sesrq_mfma_common.h"
+
+namespace sesrq {
+
+constexpr int TW = 64;            // computed columns per strip
+constexpr int TV = 60;            // valid output columns per strip
+constexpr int TH = 8;             // rows per step
+constexpr int TP = 66;            // LDS row pitch (pixels): computed columns -1 .. 64
+constexpr int TR = TH + 2;        // rows per LDS window
+constexpr int OOB = (int)0x80000000;
+
+struct TrioStage {
+    static constexpr int NIT = 3;         // 660 pixels (cold: 10 rows) or 528 (steady: 8 rows) over 256 threads
+    v4u v[NIT];
+    bool ok[NIT];
+    int voff[NIT], ty[NIT], tx[NIT];
+    int voff2s;                           // steady form of iteration 2: rows 8, 9 are not loaded
+    __amdgpu_buffer_rsrc_t rs;
+    int row_bytes;
+    __device__ __forceinline__ void init(const TrioArgs &a, int n_img, int x0, int tid) {
+        const size_t img = (size_t)a.H * a.W * 16;
+        rs = __builtin_amdgcn_make_buffer_rsrc((char *)const_cast<void *>(a.in) + (size_t)n_img * img, 0, (int)img, 0x00020000);
+        row_bytes = a.W * 16;
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int i = tid + it * 256;
+            ty[it] = i / TP;
+            tx[it] = i - ty[it] * TP;
+            const int gx = x0 - 1 + tx[it];
+            const bool okx = (gx >= 0) & (gx < a.W) & (i < TR * TP);
+            voff[it] = okx ? (ty[it] * a.W + gx) * 16 : OOB;
+            if (!okx) ty[it] = -(1 << 20);          // never a valid row -> pad
+        }
+        voff2s = (ty[2] < TH) ? voff[2] : OOB;
+    }
+    // rows [y, y + nrows) of the frame.  COLD: any y (lane-form offsets, rows above the frame pushed out of range);
+    // steady: y > 0, one scalar offset per step (gfx950 range-checks voffset + soffset)
+    template <bool COLD>
+    __device__ __forceinline__ void load(const TrioArgs &a, int y) {
+        constexpr int nrows = COLD ? TR : TH;
+        const int lo = -y, hi = min(a.H - y, nrows);
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            ok[it] = (ty[it] >= lo) & (ty[it] < hi);
+            if constexpr (COLD) v[it] = __builtin_amdgcn_raw_buffer_load_b128(rs, ok[it] ? voff[it] + y * row_bytes : OOB, 0, 0);
+            else v[it] = __builtin_amdgcn_raw_buffer_load_b128(rs, it == 2 ? voff2s : voff[it], y * row_bytes, 0);
+        }
+    }
+    template <bool COLD>
+    __device__ __forceinline__ void store(int4 *win, int pad_word, int tid) const {
+        constexpr int nrows = COLD ? TR : TH, pos0 = COLD ? 0 : 2;
+        const unsigned pw = (unsigned)pad_word;
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int i = tid + it * 256;
+            const v4u pad = {pw, pw, pw, pw};
+            const v4u t = ok[it] ? v[it] : pad;
+            if (i < nrows * TP) win[pos0 * TP + i] = make_int4((int)t[0], (int)t[1], (int)t[2], (int)t[3]);
+        }
+    }
+};
+
+struct TrioEpiC {           // the field names the shared epilogues read
+    float Mf, sh, z_next, Mres, shres, z_merge;
+};
+
+template <int EPI_C>
+__global__ __launch_bounds__(256) void mfma_trio_kernel(const TrioArgs a) {
+    __shared__ int4 bufI[TR * TP + 2], bufA[TR * TP + 2], bufB[TR * TP + 2];      // + 2: lane group 3 over-reads one pixel
+    const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, n = l & 15, g = l >> 4;
+    const int n_img = blockIdx.z;
+    const int x0 = blockIdx.x * TV - 2;              // frame column of computed column 0
+    const int steps_total = (a.H + TH - 1) / TH;
+    const int s_begin = blockIdx.y * a.chunk_steps, s_end = min(s_begin + a.chunk_steps, steps_total);
+    if (s_begin >= s_end) return;
+
+    const int c = 16 * w + n, gx = x0 + c;
+    const bool col_in = (gx >= 0) & (gx < a.W);                   // inner layers: inside the frame, else pad
+    const bool col_out = (c >= 2) & (c < 2 + TV) & (gx < a.W);    // valid output columns of the strip
+    const int rdcol = c + g;                                       // window pixel of tap kx = g (window column = computed column + 1)
+    const int wrcol = (c + 1) * 4 + g;                             // window dword of this lane's output word
+
+    v4i A[3][3], acc0[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const int4 ac = a.l[k].afrag[g];
+        acc0[k] = (v4i){ac.x + MAGIC_I, ac.y + MAGIC_I, ac.z + MAGIC_I, ac.w + MAGIC_I};     // add constant + cvt-free requant bias
+#pragma unroll
+        for (int f = 0; f < 3; ++f) A[k][f] = ld_frag(a.l[k].afrag + 4 + f * 64 + l);
+    }
+    const size_t img = (size_t)a.H * a.W * 16;
+    RowIO io;
+    io.out = __builtin_amdgcn_make_buffer_rsrc((char *)a.out + (size_t)n_img * img, 0, (int)img, 0x00020000);
+    io.rc_in = __builtin_amdgcn_make_buffer_rsrc((char *)const_cast<void *>(a.rc_in) + (size_t)n_img * img, 0, (int)img, 0x00020000);
+    io.rc_out = io.out;
+    io.row_bytes = a.W * 16;
+    const int voff_c = col_out ? (g * a.W + gx) * 16 : OOB;       // + Y * row_bytes per step
+    const TrioEpiC ec = {a.l[2].Mf, a.l[2].sh, a.l[2].z_next, a.Mres, a.shres, a.z_merge};
+
+    // inner layer K: window position 2+i <- positions i .. i+2 of the source window; row0 = frame row of i = 0
+    auto inner = [&](auto KC, auto I0, const int4 *src, int4 *dst, int row0) __attribute__((always_inline)) {
+        constexpr int K = decltype(KC)::value, i0 = decltype(I0)::value;
+        const TrioLayer &L = a.l[K];
+        const int4 *p = src + rdcol;
+        unsigned *d = reinterpret_cast<unsigned *>(dst) + wrcol;
+        v4i B0 = ld_frag(p + (i0)*TP), B1 = ld_frag(p + (i0 + 1) * TP);
+#pragma unroll
+        for (int i = i0; i < TH; ++i) {
+            const v4i B2 = ld_frag(p + (i + 2) * TP);
+            v4i acc = mfma(A[K][0], B0, acc0[K]);
+            acc = mfma(A[K][1], B1, acc);
+            acc = mfma(A[K][2], B2, acc);
+            B0 = B1; B1 = B2;
+            const int s[4] = {acc[0], acc[1], acc[2], acc[3]};
+            unsigned q = epi_mid<true>(s, L, L.zlo);
+            const int row = row0 + i;
+            const bool rok = (row >= 0) & (row < a.H);
+            q = (rok & col_in) ? q : (unsigned)L.pad_next;
+            d[(2 + i) * TP * 4] = q;
+        }
+    };
+    // outer layer: output rows Y .. Y+7 from window positions 0 .. 9 of layer b
+    auto outer = [&](int Y) __attribute__((always_inline)) {
+        const int4 *p = bufB + rdcol;
+        io.voff = col_out ? voff_c + Y * io.row_bytes : OOB;
+        v4i B0 = ld_frag(p), B1 = ld_frag(p + TP);
+#pragma unroll
+        for (int y4 = 0; y4 < TH; y4 += 4) {
+            int s4[4][4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const v4i B2 = ld_frag(p + (y4 + r + 2) * TP);
+                v4i acc = mfma(A[2][0], B0, acc0[2]);
+                acc = mfma(A[2][1], B1, acc);
+                acc = mfma(A[2][2], B2, acc);
+                B0 = B1; B1 = B2;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) s4[r][i] = acc[i];
+            }
+            emit_rows4<EPI_C, false, true>(s4, ec, io, y4, a.l[2].zlo);
+        }
+    };
+    using std::integral_constant;
+    auto shift = [&](int4 *win) __attribute__((always_inline)) {      // rows TH, TH+1 of a window -> rows 0, 1
+        if (tid < 2 * TP) { const int4 t = win[TH * TP + tid]; win[tid] = t; }
+    };
+
+    TrioStage st;
+    st.init(a, n_img, x0, tid);
+    // ---- cold start: the step before the chunk's first one, only the rows the first real step needs
+    {
+        const int Y = (s_begin - 1) * TH;
+        st.load<true>(a, Y + 1);
+        st.store<true>(bufI, a.pad_in, tid);
+        __syncthreads();
+        st.load<false>(a, Y + TH + 3);
+        inner(integral_constant<int, 0>(), integral_constant<int, 4>(), bufI, bufA, Y + 2);
+        int4 shI = make_int4(0, 0, 0, 0);
+        if (tid < 2 * TP) shI = bufI[TH * TP + tid];
+        __syncthreads();
+        if (tid < 2 * TP) bufI[tid] = shI;
+        st.store<false>(bufI, a.pad_in, tid);
+        inner(integral_constant<int, 1>(), integral_constant<int, 6>(), bufA, bufB, Y + 1);
+        __syncthreads();
+        shift(bufA);
+        __syncthreads();
+    }
+    for (int s = s_begin; s < s_end; ++s) {
+        const int Y = s * TH;
+        const bool more = s + 1 < s_end;
+        if (more) st.load<false>(a, Y + TH + 3);                 // next step's new input rows, consumed after the first barrier
+        shift(bufB);                                             // layer-b rows Y-1, Y (phase c of the previous step is done)
+        inner(integral_constant<int, 0>(), integral_constant<int, 0>(), bufI, bufA, Y + 2);
+        int4 shI = make_int4(0, 0, 0, 0);
+        if (tid < 2 * TP) shI = bufI[TH * TP + tid];
+        __syncthreads();
+        if (more) {
+            if (tid < 2 * TP) bufI[tid] = shI;
+            st.store<false>(bufI, a.pad_in, tid);
+        }
+        inner(integral_constant<int, 1>(), integral_constant<int, 0>(), bufA, bufB, Y + 1);
+        __syncthreads();
+        shift(bufA);
+        outer(Y);
+        __syncthreads();
+    }
+}
+
+// One round of workgroups that fits the chip (same sizing rule as the per-layer kernels, sesrq_mfma.hip): process-static
+// device properties, i.e. one process drives one device (the package's process-per-GPU model, sesrq/dist.py).
+template <typename K>
+static void launch_trio_k(K kern, TrioArgs a, hipStream_t st) {
+    static std::mutex mu;
+    static std::map<const void *, int> occ;
+    static int num_cu = 0;
+    int blocks_per_cu;
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        if (!num_cu) {
+            int dev = 0;
+            hipDeviceProp_t prop;
+            if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) num_cu = prop.multiProcessorCount;
+            if (num_cu < 1) num_cu = 256;
+        }
+        auto it = occ.find((const void *)kern);
+        if (it == occ.end()) {
+            int b = 0;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, kern, 256, 0) != hipSuccess || b < 1) b = 2;
+            it = occ.emplace((const void *)kern, b).first;
+        }
+        blocks_per_cu = it->second;
+    }
+    const int strips = (a.W + TV - 1) / TV, steps = (a.H + TH - 1) / TH;
+    long long k = (a.wg_budget > 0 ? (long long)a.wg_budget : (long long)blocks_per_cu * num_cu) / ((long long)strips * a.N);
+    k = std::max(1LL, std::min<long long>(k, steps));
+    a.chunk_steps = (int)((steps + k - 1) / k);
+    dim3 grid(strips, (steps + a.chunk_steps - 1) / a.chunk_steps, a.N);
+    hipLaunchKernelGGL(kern, grid, dim3(256), 0, st, a);
+}
+
+int launch_trio(const TrioArgs &a, int epi_c, hipStream_t st) {
+    if ((size_t)a.H * a.W * 16 >= ((size_t)1 << 28)) { set_error("trio: frame too large for 32-bit buffer offsets (H*W must stay below 2^24 pixels)"); return 1; }
+    if (epi_c == EPI_PRERES) launch_trio_k(mfma_trio_kernel<EPI_PRERES>, a, st);
+    else if (epi_c == EPI_MID) launch_trio_k(mfma_trio_kernel<EPI_MID>, a, st);
+    else { set_error("trio: the third layer must be a hidden layer"); return 1; }
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { set_error(std::string("trio launch failed: ") + hipGetErrorString(e)); return 1; }
+    return 0;
+}
+
+}  // namespace sesrq

@@ -15,8 +15,8 @@ LIB_PATH = os.environ.get("SESRQ_LIB") or os.path.normpath(os.path.join(_HERE, "
 MAX_LAYERS = 16
 MAX_CH = 16
 F32, I8 = 0, 1
-ENGINE_AUTO, ENGINE_DOT4, ENGINE_MFMA, ENGINE_FUSED = 0, 1, 2, 3
-OPT_ENGINE, OPT_FORCE_GENERAL, OPT_EXACT_DIV, OPT_ANCHOR_ADD = 1, 2, 3, 4
+ENGINE_AUTO, ENGINE_DOT4, ENGINE_MFMA = 0, 1, 2
+ABI_VERSION = 2
 
 
 class LayerDesc(C.Structure):
@@ -32,6 +32,12 @@ class NetDesc(C.Structure):
                 ("pe_add_bits", C.c_int32)]
 
 
+class Options(C.Structure):
+    _fields_ = [("engine", C.c_int32), ("force_general", C.c_int32), ("exact_div", C.c_int32),
+                ("anchor_add", C.c_int32), ("fuse_hidden", C.c_int32), ("wg_budget", C.c_int32),
+                ("i8_in_scale", C.c_float), ("i8_in_zero", C.c_int32)]
+
+
 class CalibConvDesc(C.Structure):
     _fields_ = [("k", C.c_int32), ("ic", C.c_int32), ("oc", C.c_int32), ("w", C.c_void_p), ("qbias", C.c_void_p),
                 ("in_scale", C.c_float), ("in_zero", C.c_int32), ("ss", C.c_float), ("acc_lo", C.c_float),
@@ -40,14 +46,15 @@ class CalibConvDesc(C.Structure):
 
 class Taps(C.Structure):
     _fields_ = [("act", C.c_void_p * MAX_LAYERS), ("pe_out", C.c_void_p * MAX_LAYERS),
-                ("pe_add", C.c_void_p * MAX_LAYERS)]
+                ("pe_add", C.c_void_p * MAX_LAYERS), ("overflow", C.c_void_p)]
 
 
 # every symbol include/sesrq.h declares: name -> (restype, argtypes)
 SYMBOLS = {
-    "sesrq_create": (C.c_int, [C.POINTER(NetDesc), C.POINTER(C.c_void_p)]),
+    "sesrq_default_options": (None, [C.POINTER(Options)]),
+    "sesrq_create": (C.c_int, [C.POINTER(NetDesc), C.POINTER(Options), C.POINTER(C.c_void_p)]),
     "sesrq_destroy": (None, [C.c_void_p]),
-    "sesrq_set_option": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
+    "sesrq_launch_plan": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "sesrq_fast_division_proven": (C.c_int, [C.c_void_p]),
     "sesrq_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_int, C.c_int, C.c_int]),
     "sesrq_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,

@@ -24,6 +24,37 @@ def shard(num_frames: int, world: int, rank: int) -> range:
     return range(start, start + base + (1 if rank < extra else 0))
 
 
+def run_timed(group: "Group", step, steps: int, warmup: int, repeats: int = 1, sync=None, units_per_step: float = 1.0):
+    """The measurement loop of bench.py, shared with the CPU tests so that on a multi-GPU node the RCCL backend is
+    the only line that has not run before:  W untimed warm-up steps, then `repeats` blocks of EXACTLY `steps` steps,
+    each block bracketed by  sync() -> barrier  on both sides (local queue drained first, then the rendezvous, so every
+    rank starts its clock with an idle device and stops it when ITS work is done and all ranks have arrived); the
+    block's time is the MAX over ranks.  `units_per_step` = units (frames) THIS rank processes per step; the job's
+    rate is the sum over ranks of units / the max-over-ranks time.  No data-path collective.
+
+    Returns {"elapsed": [s per block], "units_per_step_total": sum over ranks, "rates": [units/s per block]}."""
+    import time
+    sync = sync or (lambda: None)
+
+    def fence():
+        sync()
+        group.barrier()
+
+    for _ in range(warmup):
+        step()
+    elapsed = []
+    for _ in range(max(1, repeats)):
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        fence()
+        elapsed.append(group.max_over_ranks(time.perf_counter() - t0))
+    total_units = group.sum_over_ranks(units_per_step)
+    return {"elapsed": elapsed, "units_per_step_total": total_units,
+            "rates": [steps * total_units / e for e in elapsed]}
+
+
 class Group:
     """Thin wrapper over torch.distributed used by bench.py; a no-op for world_size 1."""
 

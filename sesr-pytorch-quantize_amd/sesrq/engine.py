@@ -17,7 +17,10 @@ class Engine:
     the workspace for a given (N, H, W) exists."""
 
     def __init__(self, bundle: Bundle, device: Optional[torch.device] = None, engine: int = _lib.ENGINE_AUTO,
-                 force_general: bool = False, exact_division: bool = False, anchor_add: bool = False):
+                 force_general: bool = False, exact_division: bool = False, anchor_add: bool = False,
+                 fuse_hidden: bool = True, wg_budget: int = 0, upstream: Optional[Bundle] = None):
+        """upstream: the net whose int8 OUTPUT frames this engine takes as int8 input (chained nets, e.g. nrdm_6 ->
+        SESR-x2): they are re-quantised into this net's input domain while the first layer stages them."""
         if not torch.cuda.is_available():
             raise RuntimeError("sesrq.Engine needs a HIP device (torch.cuda.is_available() is False); "
                                "there is no CPU fallback in this package")
@@ -39,18 +42,22 @@ class Engine:
                             scale_in=float(np.float32(bundle.scale[0])), scale_out=float(np.float32(bundle.scale[L])),
                             M_res=bundle.M_res, n_res=bundle.n_res, pixel_shuffle=bundle.pixel_shuffle,
                             pe_num=bundle.pe_num, pe_acc_bits=bundle.pe_acc_bits, pe_add_bits=bundle.pe_add_bits)
+        # options are part of sesrq_create: the device net is immutable afterwards
+        opts = _lib.Options()
+        _lib.lib().sesrq_default_options(C.byref(opts))
+        opts.engine = int(engine)
+        opts.force_general = int(bool(force_general))
+        opts.exact_div = int(bool(exact_division))
+        opts.anchor_add = int(bool(anchor_add))
+        opts.fuse_hidden = int(bool(fuse_hidden))
+        opts.wg_budget = int(wg_budget)
+        if upstream is not None:
+            opts.i8_in_scale = float(np.float32(upstream.scale[upstream.L]))
+            opts.i8_in_zero = int(upstream.zero[upstream.L])
         handle = C.c_void_p()
         with torch.cuda.device(self.device):
-            _lib.check(_lib.lib().sesrq_create(C.byref(desc), C.byref(handle)), ValueError)
+            _lib.check(_lib.lib().sesrq_create(C.byref(desc), C.byref(opts), C.byref(handle)), ValueError)
         self._h = handle
-        if engine != _lib.ENGINE_AUTO:
-            _lib.check(_lib.lib().sesrq_set_option(self._h, _lib.OPT_ENGINE, engine), ValueError)
-        if force_general:
-            _lib.check(_lib.lib().sesrq_set_option(self._h, _lib.OPT_FORCE_GENERAL, 1), ValueError)
-        if anchor_add:
-            _lib.check(_lib.lib().sesrq_set_option(self._h, _lib.OPT_ANCHOR_ADD, 1), ValueError)
-        if exact_division:
-            _lib.check(_lib.lib().sesrq_set_option(self._h, _lib.OPT_EXACT_DIV, 1), ValueError)
         self._ws: Dict[tuple, torch.Tensor] = {}
 
     def close(self):
@@ -71,6 +78,13 @@ class Engine:
     def layer_engines(self):
         return [(_lib.lib().sesrq_layer_engine(self._h, k) or b"").decode() for k in range(self.bundle.L)]
 
+    def launch_plan(self):
+        """[(first_layer, n_layers)] per kernel launch of forward() (n_layers == 3: fused hidden trio)."""
+        L = self.bundle.L
+        first, count = (C.c_int * L)(), (C.c_int * L)()
+        n = _lib.lib().sesrq_launch_plan(self._h, first, count)
+        return [(first[i], count[i]) for i in range(n)]
+
     def out_shape(self, N, H, W):
         r = self.bundle.pixel_shuffle
         return (N, self.bundle.out_channels, H * r, W * r)
@@ -85,6 +99,20 @@ class Engine:
             ws = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
             self._ws[key] = ws
         return ws
+
+    def _enter_stream(self, stream, *tensors):
+        """Resolve the stream to launch on.  A side stream is ordered after the work already queued on the
+        current stream (which may still be producing `x` or own the memory of freshly allocated outputs),
+        and every tensor the launch touches is recorded on it so the caching allocator does not recycle it
+        while the kernels run."""
+        cur = torch.cuda.current_stream(self.device)
+        if stream is None or stream == cur:
+            return cur
+        stream.wait_stream(cur)
+        for t in tensors:
+            if t is not None:
+                t.record_stream(stream)
+        return stream
 
     def _check_in(self, x: torch.Tensor):
         if x.dim() != 4:
@@ -107,61 +135,71 @@ class Engine:
         stream: torch.cuda.Stream to enqueue on (default: current); slot: workspace copy to use -- give
         concurrent in-flight frames different slots."""
         dt = self._check_in(x)
-        x = x.contiguous()
-        N, _, H, W = x.shape
-        shp = self.out_shape(N, H, W)
-        if want_q and out_q is None:
-            out_q = torch.empty(shp, dtype=torch.int8, device=self.device)
-        if want_f and out_f is None:
-            out_f = torch.empty(shp, dtype=torch.float32, device=self.device)
-        ws = self.workspace(N, H, W, slot)
-        st = (stream if stream is not None else torch.cuda.current_stream(self.device)).cuda_stream
-        rc = _lib.lib().sesrq_forward(self._h, x.data_ptr(), dt, out_q.data_ptr() if out_q is not None else None,
-                                      out_f.data_ptr() if out_f is not None else None, N, H, W, ws.data_ptr(),
-                                      ws.numel(), st)
+        with torch.cuda.device(self.device):
+            x = x.contiguous()
+            N, _, H, W = x.shape
+            shp = self.out_shape(N, H, W)
+            if want_q and out_q is None:
+                out_q = torch.empty(shp, dtype=torch.int8, device=self.device)
+            if want_f and out_f is None:
+                out_f = torch.empty(shp, dtype=torch.float32, device=self.device)
+            ws = self.workspace(N, H, W, slot)
+            st = self._enter_stream(stream, x, out_q, out_f, ws).cuda_stream
+            rc = _lib.lib().sesrq_forward(self._h, x.data_ptr(), dt, out_q.data_ptr() if out_q is not None else None,
+                                          out_f.data_ptr() if out_f is not None else None, N, H, W, ws.data_ptr(),
+                                          ws.numel(), st)
         _lib.check(rc)
         return out_q, out_f
 
     __call__ = forward
 
     def forward_timed(self, x: torch.Tensor, iters: int = 10):
-        """Measurement hook (sesrq_forward_timed): average device ms per layer launch and per forward."""
+        """Measurement hook (sesrq_forward_timed): average device ms per kernel launch (see launch_plan())
+        and per forward, HIP events on the launch stream."""
         dt = self._check_in(x)
-        x = x.contiguous()
-        N, _, H, W = x.shape
-        shp = self.out_shape(N, H, W)
-        out_q = torch.empty(shp, dtype=torch.int8, device=self.device)
-        ws = self.workspace(N, H, W)
-        st = torch.cuda.current_stream(self.device).cuda_stream
-        layer_ms = (C.c_float * self.bundle.L)()
-        fwd = C.c_float()
-        _lib.check(_lib.lib().sesrq_forward_timed(self._h, x.data_ptr(), dt, out_q.data_ptr(), None, N, H, W,
-                                                  ws.data_ptr(), ws.numel(), st, iters, layer_ms, C.byref(fwd)))
-        return list(layer_ms), float(fwd.value)
+        with torch.cuda.device(self.device):
+            x = x.contiguous()
+            N, _, H, W = x.shape
+            shp = self.out_shape(N, H, W)
+            out_q = torch.empty(shp, dtype=torch.int8, device=self.device)
+            ws = self.workspace(N, H, W)
+            st = torch.cuda.current_stream(self.device).cuda_stream
+            nl = len(self.launch_plan())
+            launch_ms = (C.c_float * nl)()
+            fwd = C.c_float()
+            _lib.check(_lib.lib().sesrq_forward_timed(self._h, x.data_ptr(), dt, out_q.data_ptr(), None, N, H, W,
+                                                      ws.data_ptr(), ws.numel(), st, iters, launch_ms, C.byref(fwd)))
+        return list(launch_ms), float(fwd.value)
 
-    def forward_debug(self, x: torch.Tensor, pe: bool = True):
+    def forward_debug(self, x: torch.Tensor, pe: bool = True, overflow: bool = False):
         """Forward with the reference's dump taps (define.py *_W_FLG): returns a dict with
-        q_out, y, input{k} (int8 NCHW), pe_out{k} (N,4,OC,H,W int32), pe_add{k} (N,OC,H,W int32)."""
+        q_out, y, input{k} (int8 NCHW), pe_out{k} (N,4,OC,H,W int32), pe_add{k} (N,OC,H,W int32) and, with
+        overflow=True, `overflow` (L,2) int32: PE sums above / below the accumulator range before saturation --
+        the events the reference prints as max_overflow / min_overflow (quan_func.py:358-361)."""
         dt = self._check_in(x)
-        x = x.contiguous()
-        N, _, H, W = x.shape
-        L = self.bundle.L
-        shp = self.out_shape(N, H, W)
-        res = {"q_out": torch.empty(shp, dtype=torch.int8, device=self.device),
-               "y": torch.empty(shp, dtype=torch.float32, device=self.device)}
-        taps = _lib.Taps()
-        for k, l in enumerate(self.bundle.layers):
-            oc, ic = l.wq.shape[0], l.wq.shape[1]
-            res[f"input{k}"] = torch.empty((N, ic, H, W), dtype=torch.int8, device=self.device)
-            taps.act[k] = res[f"input{k}"].data_ptr()
-            if pe:
-                res[f"pe_out{k}"] = torch.empty((N, 4, oc, H, W), dtype=torch.int32, device=self.device)
-                res[f"pe_add{k}"] = torch.empty((N, oc, H, W), dtype=torch.int32, device=self.device)
-                taps.pe_out[k] = res[f"pe_out{k}"].data_ptr()
-                taps.pe_add[k] = res[f"pe_add{k}"].data_ptr()
-        ws = self.workspace(N, H, W)
-        st = torch.cuda.current_stream(self.device).cuda_stream
-        rc = _lib.lib().sesrq_forward_debug(self._h, x.data_ptr(), dt, res["q_out"].data_ptr(), res["y"].data_ptr(),
-                                            N, H, W, ws.data_ptr(), ws.numel(), st, C.byref(taps))
+        with torch.cuda.device(self.device):
+            x = x.contiguous()
+            N, _, H, W = x.shape
+            L = self.bundle.L
+            shp = self.out_shape(N, H, W)
+            res = {"q_out": torch.empty(shp, dtype=torch.int8, device=self.device),
+                   "y": torch.empty(shp, dtype=torch.float32, device=self.device)}
+            taps = _lib.Taps()
+            for k, l in enumerate(self.bundle.layers):
+                oc, ic = l.wq.shape[0], l.wq.shape[1]
+                res[f"input{k}"] = torch.empty((N, ic, H, W), dtype=torch.int8, device=self.device)
+                taps.act[k] = res[f"input{k}"].data_ptr()
+                if pe:
+                    res[f"pe_out{k}"] = torch.empty((N, 4, oc, H, W), dtype=torch.int32, device=self.device)
+                    res[f"pe_add{k}"] = torch.empty((N, oc, H, W), dtype=torch.int32, device=self.device)
+                    taps.pe_out[k] = res[f"pe_out{k}"].data_ptr()
+                    taps.pe_add[k] = res[f"pe_add{k}"].data_ptr()
+            if overflow:
+                res["overflow"] = torch.zeros((L, 2), dtype=torch.int32, device=self.device)
+                taps.overflow = res["overflow"].data_ptr()
+            ws = self.workspace(N, H, W)
+            st = torch.cuda.current_stream(self.device).cuda_stream
+            rc = _lib.lib().sesrq_forward_debug(self._h, x.data_ptr(), dt, res["q_out"].data_ptr(), res["y"].data_ptr(),
+                                                N, H, W, ws.data_ptr(), ws.numel(), st, C.byref(taps))
         _lib.check(rc)
         return res

@@ -24,24 +24,23 @@ from myQL.quan_func import (quantize_model_weight, quantize_asymmetrical_by_tens
                             PEs_and_bias_adder, requan_conv2d_output)
 from myQL.quan_classes import NodeInsertMapping, FunctionPackage, NodeInsertMappingElement
 from myQL.graph_modify import insert_before, insert_bias_bypass, insert_after
-from models import sesr_sim, nrdm_3_sim, sesr_arch_sim
+from models import sesr_sim, nrdm_3_sim, sesr_arch_sim, nrdm_6
 from sesrq.store import STORE
 
-MODELS = {3: nrdm_3_sim.nr, 5: sesr_sim.sesr, 6: sesr_arch_sim.sesr}
+# MFLAG -> net, as the reference's test_float.py:25-48 numbers them.  4 (nrdm_6, 8 convs) has no integer path in the
+# reference: roles generalise by position here, parity unpinned.
+MODELS = {3: nrdm_3_sim.nr, 4: nrdm_6.nr, 5: sesr_sim.sesr, 6: sesr_arch_sim.sesr}
 
 
 def float_model(mflag, ckpt=None, params=None):
     """Float net, collapsed.  ckpt: a reference state_dict (.pth, loaded with weights_only=True);
     params: an .npz holding already-collapsed convs Wf{k}/bf{k} (tests/golden/*.params.npz)."""
     if mflag not in MODELS:
-        raise ValueError(f"MFLAG {mflag}: only 3 (nrdm_3), 5 (SESR x4) and 6 (SESR x2) have an integer path")
+        raise ValueError(f"MFLAG {mflag}: only 3 (nrdm_3), 4 (nrdm_6), 5 (SESR x4) and 6 (SESR x2) have an integer path")
     model = MODELS[mflag]()
     model.train()
     if ckpt is not None:
-        sd = torch.load(ckpt, weights_only=True, map_location="cpu")
-        if isinstance(sd, dict) and "state_dict" in sd:
-            sd = sd["state_dict"]
-        model.load_state_dict(sd, strict=False)
+        load_checkpoint(model, ckpt, mflag)
     model.collapse()
     if params is not None:
         z = np.load(params, allow_pickle=False)
@@ -54,6 +53,39 @@ def float_model(mflag, ckpt=None, params=None):
         if "scale" in meta:
             STORE.set_activation_domains(meta["scale"], meta["zero"])
     return model
+
+
+def load_checkpoint(model, ckpt, mflag):
+    """Load a reference float checkpoint into the plain collapsible net -- strictly.
+
+    The reference only consumes a ``*_qat_G.pth`` after ``quantize.prepare()`` has wrapped every conv in a
+    QuantConv2d (reference sim.py:64-66, models/quantize_utils_pt.py:331,801): its ``collapse()`` then folds
+    through the weight / activation fake-quantisers, and the folded weights differ from a fold of the raw conv
+    weights (tens to hundreds of INT8 weights per net).  QAT modules are outside this package, so such a
+    checkpoint is REFUSED instead of being folded wrongly; the bundles the reference itself derives from them
+    are committed as tests/golden/{sesr_x4_qat,nrdm_3_qat}.params.npz (use --params).  Any other key mismatch
+    (a checkpoint of another net / --mflag) is refused as well: nothing may leave random-init weights behind."""
+    sd = torch.load(ckpt, weights_only=True, map_location="cpu")
+    if isinstance(sd, dict) and "state_dict" in sd:
+        sd = sd["state_dict"]
+    if not isinstance(sd, dict):
+        raise ValueError(f"{ckpt}: not a state_dict")
+    qat = [k for k in sd if "_quantizer." in k]
+    if qat:
+        raise ValueError(
+            f"{ckpt} is a QAT checkpoint ({len(qat)} *_quantizer.* entries, e.g. {qat[0]!r}): the reference folds it "
+            "through quantize.prepare()'s fake-quantisers (reference sim.py:64-66), which this package does not "
+            "implement -- folding the raw conv weights would give a different INT8 bundle.  Use the bundle the "
+            "reference derived from it: --params tests/golden/sesr_x4_qat.params.npz (sr_qat_G.pth) or "
+            "tests/golden/nrdm_3_qat.params.npz (nrdm_3_qat_G.pth).")
+    try:
+        res = model.load_state_dict(sd, strict=False)
+    except RuntimeError as e:           # tensor shape mismatch
+        raise ValueError(f"{ckpt} does not fit the MFLAG {mflag} net ({type(model).__module__}): {e}") from None
+    if res.missing_keys or res.unexpected_keys:
+        raise ValueError(f"{ckpt} does not fit the MFLAG {mflag} net ({type(model).__module__}): missing "
+                         f"{res.missing_keys[:3]}{'...' if len(res.missing_keys) > 3 else ''}, unexpected "
+                         f"{res.unexpected_keys[:3]}{'...' if len(res.unexpected_keys) > 3 else ''}")
 
 
 def splice(model, qmode=1):

@@ -28,16 +28,24 @@ def _free_port():
 
 def _worker(rank, world, port, q):
     import sys
+    import time
     os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-    from sesrq.dist import Group, shard as sh
+    from sesrq.dist import Group, run_timed, shard as sh
     g = Group(backend="gloo")
     mine = sh(11, g.world, g.rank)
-    # a "step" = this rank's frames through a stand-in per-frame function (no GPU here)
-    done = sum(1 for _ in mine)
-    g.barrier()
-    elapsed = g.max_over_ranks(0.5 + rank)       # rank 1 is the slow one
-    total = g.sum_over_ranks(done)
-    q.put((rank, list(mine), elapsed, total))
+    # a "step" = this rank's frames through a stand-in per-frame function (the engine is the only thing stubbed:
+    # bench.py passes Engine.forward here and torch.cuda.synchronize as `sync`)
+    log = []
+
+    def step():
+        for f in mine:
+            log.append(f)
+        time.sleep(0.02 * (1 + rank))            # rank 1 is the slow one
+
+    synced = []
+    res = run_timed(g, step, steps=3, warmup=2, repeats=2, sync=lambda: synced.append(len(log)), units_per_step=len(mine))
+    elapsed = g.max_over_ranks(0.5 + rank)
+    q.put((rank, list(mine), elapsed, res, len(log), synced))
     g.close()
 
 
@@ -52,6 +60,14 @@ def test_two_rank_gloo_fence_and_sharding():
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    assert res[0][1] + res[1][1] == list(range(11))
+    assert res[0][1] + res[1][1] == list(range(11))          # uneven shards (6 + 5), every frame exactly once
     assert all(abs(r[2] - 1.5) < 1e-12 for r in res), "MAX over ranks"
-    assert all(r[3] == 11 for r in res), "every frame processed exactly once"
+    for rank, mine, _, timed, nlog, synced in res:
+        assert timed["units_per_step_total"] == 11, "sum over ranks of the frames per step"
+        assert len(timed["elapsed"]) == 2 and nlog == len(mine) * (2 + 2 * 3), "W warm-up + repeats x K steps, exactly"
+        # both ranks report the SLOW rank's block time (3 steps x 40 ms), not their own
+        assert all(e >= 3 * 0.04 * 0.9 for e in timed["elapsed"]), timed
+        assert all(abs(a - b) < 1e-9 for a, b in zip(res[0][3]["elapsed"], res[1][3]["elapsed"]))
+        assert timed["rates"] == [3 * 11 / e for e in timed["elapsed"]]
+        # the local drain (sync) runs on both sides of every block: before the start barrier and after the last step
+        assert synced == [len(mine) * 2, len(mine) * 5, len(mine) * 5, len(mine) * 8]

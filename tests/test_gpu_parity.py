@@ -18,18 +18,14 @@ from sesrq import _lib
 pytestmark = pytest.mark.gpu
 
 STAGE_FILES = [f for f in golden_files() if not f.endswith((".params.npz", "tables.npz", ".stimtxt.npz"))]
-ENGINES = [("dot4", _lib.ENGINE_DOT4), ("mfma", _lib.ENGINE_MFMA), ("fused", _lib.ENGINE_FUSED)]
+# kernel families behind the same ABI: dot4 (one lane per pixel), mfma (one launch per layer), trio (the default: MFMA
+# kernels with every eligible run of three hidden 3x3 layers fused into one launch)
+ENGINES = [("dot4", dict(engine=_lib.ENGINE_DOT4)), ("mfma", dict(engine=_lib.ENGINE_MFMA, fuse_hidden=False)),
+           ("trio", dict(engine=_lib.ENGINE_MFMA, fuse_hidden=True))]
 
 
 def make_engine(net, eng, **kw):
-    """Engine on the requested kernel family; the fused engine only takes the reference topology
-    with zero[1] == -128 (always true after calibration: ReLU output min is 0) -> skip otherwise."""
-    try:
-        return sesrq.Engine(bundle_from_oracle(net), _dev(), engine=eng[1], **kw)
-    except ValueError as e:
-        if eng[0] == "fused" and "not eligible" in str(e):
-            pytest.skip("net not eligible for the fused engine")
-        raise
+    return sesrq.Engine(bundle_from_oracle(net), _dev(), **eng[1], **kw)
 
 
 def _sha(a):
@@ -62,7 +58,9 @@ def test_golden_stage_by_stage(path, eng):
     use_pe = eng[0] == "dot4"        # the PE dump taps are a dot4-engine feature; with them a layer runs on dot4
     res = e.forward_debug(xt, pe=use_pe)
     if eng[0] != "dot4":
-        assert all(s.startswith(eng[0]) for s in e.layer_engines()), e.layer_engines()
+        assert all(s.startswith("mfma") for s in e.layer_engines()), e.layer_engines()
+        assert ("mfma-trio-merged" in e.layer_engines()) == (eng[0] == "trio" and not any(
+            "general" in s or "hybrid" in s for s in e.layer_engines()[1:4])), e.layer_engines()
     r = net.pixel_shuffle
     got = {k: v.cpu().numpy() for k, v in res.items()}
     # un-shuffle q_out to compare with input5
@@ -80,14 +78,14 @@ def test_golden_stage_by_stage(path, eng):
     for name in fx.files:
         if name in got and name not in ("x",):
             _cmp(name, got[name], fx[name])
-    # production call (no taps; this is where the fused engine runs) must give the same result
+    # production call (no taps; this is where the fused hidden trio runs) must give the same result
     q, y = e.forward(xt)
     _cmp("q_out(production)", q, got["q_out"])
     _cmp("y(production)", y, got["y"])
     _cmp("q_out(production) vs golden input5", np.ascontiguousarray(q.cpu().numpy().reshape(N, C, Ho // r, r, Wo // r, r).transpose(0, 1, 3, 5, 2, 4).reshape(q5.shape)), fx["input5"])
 
 
-SIZES = [(1, 1, 1), (1, 3, 5), (1, 8, 32), (1, 9, 33), (2, 17, 70), (1, 40, 129), (3, 31, 64)]
+SIZES = [(1, 1, 1), (1, 3, 5), (1, 8, 32), (1, 9, 33), (2, 17, 70), (1, 40, 129), (3, 31, 64), (1, 26, 121)]
 
 
 @pytest.mark.parametrize("eng", ENGINES, ids=[e[0] for e in ENGINES])
@@ -98,8 +96,6 @@ def test_synthetic_nets_vs_oracle(kind, hard, eng):
     zero points -> general kernels with the 18/20-bit clamps firing), ragged sizes, batches."""
     for seed in range(2):
         net = O.synth_net(kind, seed, hard=hard)
-        if eng[0] == "fused":
-            net.zero[1] = -128          # the fused engine's precondition (see make_engine)
         e = make_engine(net, eng)
         cin = net.layers[0].wq.shape[1]
         for (N, H, W) in SIZES:
@@ -156,7 +152,7 @@ def test_full_size_properties_1080p():
     (c) determinism: two runs give identical bytes."""
     net = O.synth_net("sesr_x2", 0)
     e = sesrq.Engine(bundle_from_oracle(net), _dev())
-    assert all(s.startswith("mfma") for s in e.layer_engines()), "default engine = per-layer MFMA kernels"
+    assert all(s.startswith("mfma") for s in e.layer_engines()), "default engine = MFMA kernels"
     x = torch.from_numpy(rand_frame((1, 3, 1080, 1920), 2)).to(_dev())
     q, y = e.forward(x)
     q2, _ = e.forward(x)
@@ -314,12 +310,12 @@ def test_config5_shape_nrdm6_then_sesr_x2_chain():
     assert tuple(q2.shape) == (2, 3, 90, 166)
 
 
-@pytest.mark.parametrize("eng", ENGINES[:2], ids=[e[0] for e in ENGINES[:2]])
+@pytest.mark.parametrize("eng", ENGINES, ids=[e[0] for e in ENGINES])
 def test_x2_anchor_add(eng):
     """SURVEY 8f-4: the x2 eval loop adds the nearest-upsampled input to the float output (test.py:148-155);
     fused into the last epilogue as an option.  One fp32 add per output value -> bit-exact vs numpy."""
     net = O.synth_net("sesr_x2", 3)
-    e = sesrq.Engine(bundle_from_oracle(net), _dev(), engine=eng[1], anchor_add=True)
+    e = make_engine(net, eng, anchor_add=True)
     x = rand_frame((2, 3, 37, 70), 12)
     q, y = e.forward(torch.from_numpy(x).to(_dev()))
     want = O.forward(net, x)
@@ -365,3 +361,137 @@ def test_empty_and_degenerate_inputs():
     # a constant frame is fine in the integer path (only the calibration observer rejects "all equal")
     q, _ = e.forward(torch.full((1, 3, 5, 7), 0.25, device=_dev()))
     _cmp("constant frame", q, O.forward(net, np.full((1, 3, 5, 7), 0.25, np.float32))["q_out"])
+
+
+# ---------------------------------------------------------------- fused hidden trio (sesrq_trio.hip)
+
+TRIO_SHAPES = [(1, 1, 1), (1, 7, 59), (1, 8, 60), (1, 9, 61), (2, 16, 119), (1, 17, 120), (1, 23, 121), (1, 64, 180),
+               (3, 41, 250), (1, 130, 62), (2, 200, 33)]
+
+
+@pytest.mark.parametrize("budget", [0, 1, 6], ids=["one-round", "one-wg-per-strip", "budget6"])
+def test_trio_walk_shapes_and_chunking(budget):
+    """Strips of 60 valid columns, steps of 8 rows, cold chunk starts, the steady multi-step walk (wg_budget makes a
+    workgroup walk a whole strip even on small frames), frame borders inside the 3-layer halo: fused trio vs the
+    per-layer kernels vs the C oracle."""
+    from oracle import c_oracle as CO
+    for seed, kind in enumerate(["sesr_x2", "nrdm", "sesr_x4"]):
+        net = O.synth_net(kind, 40 + seed)
+        et = sesrq.Engine(bundle_from_oracle(net), _dev(), wg_budget=budget)
+        el = sesrq.Engine(bundle_from_oracle(net), _dev(), fuse_hidden=False, wg_budget=budget)
+        assert et.layer_engines()[1:4] == ["mfma-trio-merged"] * 3 and et.launch_plan() == [(0, 1), (1, 3), (4, 1)]
+        assert el.launch_plan() == [(k, 1) for k in range(5)]
+        cin = net.layers[0].wq.shape[1]
+        for (N, H, W) in TRIO_SHAPES:
+            x = rand_frame((N, cin, H, W), 31 * H + W)
+            xt = torch.from_numpy(x).to(_dev())
+            q, y = et.forward(xt)
+            q2, y2 = el.forward(xt)
+            want = CO.forward(net, x)
+            _cmp(f"{net.name} {N}x{H}x{W} budget {budget}: trio vs oracle", q, want["q_out"])
+            _cmp(f"{net.name} {N}x{H}x{W} budget {budget}: per-layer vs oracle", q2, want["q_out"])
+            _cmp("y", y, want["y"])
+
+
+def test_trio_with_separate_residual_tensor_and_odd_zero_points():
+    """zero[1] != -128: the residual operand is its own tensor (layer 0 writes it); pad values of the inner layers
+    differ per layer (zc = max(zero, -128)); zero points above -128 on the hidden domains."""
+    net = O.synth_net("sesr_x2", 51)
+    net.zero[1], net.zero[2], net.zero[3], net.zero[4] = -120, -101, -128, -77
+    e = sesrq.Engine(bundle_from_oracle(net), _dev(), wg_budget=2)
+    assert "mfma-trio-merged" in e.layer_engines()
+    for (N, H, W) in [(1, 19, 70), (2, 33, 121)]:
+        x = rand_frame((N, 3, H, W), H)
+        want = O.forward(net, x)
+        q, y = e.forward(torch.from_numpy(x).to(_dev()))
+        _cmp("q_out", q, want["q_out"])
+
+
+def test_trio_on_deeper_net_two_trios():
+    """8-conv net (nrdm_6 shape): hidden layers 1-3 run as a trio with a plain third epilogue, 4-6 as the trio that
+    merges the residual.  Parity unpinned w.r.t. the reference (no integer path at this depth): oracle vs HIP."""
+    net = O.synth_net("nrdm", 61, n_blocks=6)
+    e = sesrq.Engine(bundle_from_oracle(net), _dev(), wg_budget=3)
+    assert e.launch_plan() == [(0, 1), (1, 3), (4, 3), (7, 1)], e.launch_plan()
+    x = rand_frame((2, 3, 45, 130), 8)
+    want = O.forward(net, x)
+    q, y = e.forward(torch.from_numpy(x).to(_dev()))
+    _cmp("q_out", q, want["q_out"])
+    _cmp("y", y, want["y"])
+
+
+# ---------------------------------------------------------------- full frames at the BASELINE sizes
+
+def _full_frame_case(fixture, shape, seed, engines_expected, **kw):
+    from oracle import c_oracle as CO
+    fx, meta, net, _ = fixture_case(os.path.join(os.path.dirname(STAGE_FILES[0]), fixture))
+    e = sesrq.Engine(bundle_from_oracle(net), _dev(), **kw)
+    assert e.layer_engines() == engines_expected, e.layer_engines()
+    x = rand_frame(shape, seed)
+    q, _ = e.forward(torch.from_numpy(x).to(_dev()))
+    want = CO.forward(net, x, want_f=False)["q_out"]
+    _cmp(f"{fixture} {shape} whole frame vs C oracle", q, want)
+    return e, x, q
+
+
+def test_config2_full_frame_1080p_on_the_timed_kernels():
+    """BASELINE config 2 on the bundle bench.py times (reference random-init x2 net calibrated by the reference):
+    the WHOLE 1x3x1080x1920 -> 3x2160x3840 frame against the C oracle, borders (pad value zc,
+    myQL/quan_func.py:351-356) and every chunk boundary of the full-chip grid included; the same frame on the
+    per-layer kernels must give the same bytes."""
+    names = ["mfma-f5-hybrid", "mfma-trio-merged", "mfma-trio-merged", "mfma-trio-merged", "mfma-h5-general"]
+    e, x, q = _full_frame_case("sesr_x2_rand.crop.npz", (1, 3, 1080, 1920), 1, names)
+    e2 = sesrq.Engine(e.bundle, _dev(), fuse_hidden=False)
+    assert e2.layer_engines() == ["mfma-f5-hybrid", "mfma-h3-merged", "mfma-h3-merged", "mfma-h3-merged", "mfma-h5-general"]
+    q2, _ = e2.forward(torch.from_numpy(x).to(_dev()))
+    assert torch.equal(q, q2)
+
+
+def test_config3_full_frame_nrdm3_540p():
+    """BASELINE config 3: nrdm_3 (reference checkpoint, reference calibration) 1x3x540x960, whole frame."""
+    _full_frame_case("nrdm_3.crop.npz", (1, 3, 540, 960), 3,
+                     ["mfma-f5-merged", "mfma-trio-merged", "mfma-trio-merged", "mfma-trio-merged", "mfma-h5p-merged"])
+
+
+def test_batch_larger_than_one_chip_round():
+    """N x strips exceeds the workgroup slots of the chip: every workgroup walks a whole strip (chunk = all tiles)."""
+    from oracle import c_oracle as CO
+    fx, meta, net, _ = fixture_case(os.path.join(os.path.dirname(STAGE_FILES[0]), "sesr_x2_rand.crop.npz"))
+    e = sesrq.Engine(bundle_from_oracle(net), _dev())
+    x = rand_frame((72, 3, 36, 1030), 5)          # 72 frames x 18 strips (60 columns) / 17 (64 columns) > 1024 slots
+    q, _ = e.forward(torch.from_numpy(x).to(_dev()))
+    want = CO.forward(net, x, want_f=False)["q_out"]
+    _cmp("72 x 36 x 1030", q, want)
+
+
+def test_side_stream_with_non_contiguous_input():
+    """forward(stream=s): the side stream is ordered behind the producer of x, temporaries are recorded on it."""
+    net = O.synth_net("sesr_x2", 9)
+    e = sesrq.Engine(bundle_from_oracle(net), _dev())
+    base = torch.from_numpy(rand_frame((2, 3, 50, 140), 3)).to(_dev())
+    xnc = base.transpose(2, 3).contiguous().transpose(2, 3)       # same values, non-contiguous view
+    assert not xnc.is_contiguous()
+    s = torch.cuda.Stream(device=_dev())
+    q, y = e.forward(xnc, stream=s)
+    s.synchronize()
+    want = O.forward(net, base.cpu().numpy())
+    _cmp("q_out", q, want["q_out"])
+    _cmp("y", y, want["y"])
+
+
+def test_overflow_counters_mirror_the_reference_prints():
+    """sesrq_taps.overflow counts PE sums outside the 18-bit accumulator range before saturation -- the events the
+    reference prints as max_overflow / min_overflow (myQL/quan_func.py:358-361); golden: the saturating-weight
+    fixtures made the reference print them, the ordinary ones did not."""
+    for tag, expect in (("sesr_x4.crop.npz", False), ("sesr_x4.satw.npz", True)):
+        fx, meta, net, x = fixture_case(os.path.join(os.path.dirname(STAGE_FILES[0]), tag))
+        e = sesrq.Engine(bundle_from_oracle(net), _dev())
+        res = e.forward_debug(torch.from_numpy(x).to(_dev()), pe=False, overflow=True)
+        ovf = res["overflow"].cpu().numpy()
+        st = O.forward(net, x, keep=True)
+        for k in range(net.L if hasattr(net, "L") else len(net.layers)):
+            raw = st.get(f"pe_raw{k}")
+            if raw is not None:
+                assert ovf[k, 0] == int((raw > 131071).sum()) and ovf[k, 1] == int((raw < -131072).sum())
+        assert bool(ovf.any()) == expect, (tag, ovf)
+        _cmp("q_out with the counter tap", res["q_out"], st["q_out"])

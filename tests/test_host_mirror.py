@@ -159,3 +159,62 @@ def test_calibrate_then_infer_end_to_end():
     net = O.Net(layers=[O.Layer(l.wq, l.add_const, l.M, l.n, l.relu) for l in b.layers], scale=b.scale, zero=b.zero,
                 M_res=b.M_res, n_res=b.n_res, pixel_shuffle=b.pixel_shuffle)
     np.testing.assert_array_equal(y.cpu().numpy(), O.forward(net, x)["y"])
+
+
+def _plain_state_dict(mflag):
+    torch.manual_seed(3)
+    return sim.MODELS[mflag]().state_dict()
+
+
+def test_qat_checkpoint_is_refused_loudly(tmp_path):
+    """A *_qat_G.pth carries weight_quantizer / activation_quantizer state that the reference consumes through
+    quantize.prepare() (reference sim.py:64-66); folding its raw conv weights would give another INT8 bundle
+    (45..1129 differing weights).  float_model must refuse it and point to the golden bundles."""
+    sd = _plain_state_dict(5)
+    sd["conv_first.conv_expand.weight_quantizer.scale"] = torch.ones(1)
+    sd["conv_first.conv_expand.activation_quantizer.observer.min_val"] = torch.zeros(1)
+    p = tmp_path / "fake_qat_G.pth"
+    torch.save(sd, p)
+    with pytest.raises(ValueError, match=r"QAT checkpoint.*--params"):
+        sim.float_model(5, ckpt=str(p))
+    # the calibration entry goes through the same loader
+    import test as calib_entry
+    with pytest.raises(ValueError, match="QAT checkpoint"):
+        calib_entry.sim.float_model(5, ckpt=str(p))
+
+
+def test_checkpoint_of_another_net_is_refused(tmp_path):
+    p = tmp_path / "nrdm3.pth"
+    torch.save(_plain_state_dict(3), p)
+    with pytest.raises(ValueError, match="does not fit the MFLAG 5 net"):
+        sim.float_model(5, ckpt=str(p))               # 3-channel first conv into the 1-channel x4 net
+    p6 = tmp_path / "nrdm6.pth"
+    torch.save(_plain_state_dict(4), p6)
+    with pytest.raises(ValueError, match="unexpected"):
+        sim.float_model(3, ckpt=str(p6))              # 6 residual blocks into the 3-block net
+    sim.float_model(3, ckpt=str(p))                   # the right one loads
+
+
+REF_PARAMS = "/root/reference/model_params"
+
+
+@pytest.mark.skipif(not os.path.isdir(REF_PARAMS), reason="reference checkpoints not present (build container only)")
+@pytest.mark.parametrize("name", ["sr_qat_G.pth", "nrdm_3_qat_G.pth", "nrdm_6_qat_G.pth"])
+def test_reference_qat_checkpoints_are_refused(name):
+    mflag = {"sr_qat_G.pth": 5, "nrdm_3_qat_G.pth": 3, "nrdm_6_qat_G.pth": 4}[name]
+    with pytest.raises(ValueError, match="QAT checkpoint"):
+        sim.float_model(mflag, ckpt=os.path.join(REF_PARAMS, name))
+
+
+@pytest.mark.skipif(not os.path.isdir(REF_PARAMS), reason="reference checkpoints not present (build container only)")
+@pytest.mark.parametrize("ckpt,mflag,case", [("x4sesr.pth", 5, "sesr_x4"), ("nrdm_3_raw_G.pth", 3, "nrdm_3")])
+def test_reference_float_checkpoint_gives_the_golden_int8_weights(ckpt, mflag, case):
+    """--ckpt path end to end on the host: load (strict) -> closed-form collapse -> weight quantiser == the Wq the
+    reference produced from the same checkpoint (0 mismatching INT8 weights)."""
+    STORE.clear()
+    fx, meta = load_fixture(os.path.join(GOLDEN, f"{case}.crop.npz"))
+    STORE.set_activation_domains(meta["scale"], meta["zero"])
+    model = sim.splice(sim.float_model(mflag, ckpt=os.path.join(REF_PARAMS, ckpt)))
+    b = model.sesrq_bundle()
+    for k in range(5):
+        np.testing.assert_array_equal(b.layers[k].wq, fx[f"Wq{k}"])
