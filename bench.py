@@ -105,7 +105,9 @@ def main():
     bundles = [Bundle.load(os.path.join(ROOT, "tests", "golden", f)) for f in fixtures]
     ekw = dict(engine={"auto": _lib.ENGINE_AUTO, "dot4": _lib.ENGINE_DOT4, "mfma": _lib.ENGINE_MFMA}[args.engine],
                fuse_hidden=not args.no_fuse, wg_budget=args.wg_budget)
-    engines = [sesrq.Engine(b, dev, **ekw) for b in bundles]
+    # chained nets: every net but the first takes the int8 output of the one before and re-quantises it into its own
+    # input domain while staging (sesrq_options.i8_in_scale / i8_in_zero) -- no fp32 round trip through HBM
+    engines = [sesrq.Engine(b, dev, upstream=(bundles[j - 1] if j else None), **ekw) for j, b in enumerate(bundles)]
     if mode == "total":                          # strong scaling: a fixed batch cut into contiguous per-rank blocks
         mine = shard(args.batch or nframes, world, rank)
         B = len(mine)
@@ -182,7 +184,9 @@ def main():
         # ---- parity: the WHOLE first frame of the pool against the C oracle (checker only), which doubles as the CPU baseline
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         from oracle import sesrq_oracle as O, c_oracle as CO
-        onets = [O.net_from_fixture(np.load(os.path.join(ROOT, "tests", "golden", f), allow_pickle=False)) for f in fixtures]
+        onets = [O.Net(layers=[O.Layer(wq=l.wq, add_const=l.add_const, M=l.M, n=l.n, relu=l.relu) for l in b.layers],
+                       scale=b.scale, zero=b.zero, M_res=b.M_res, n_res=b.n_res, pixel_shuffle=b.pixel_shuffle, pe=b.pe_num,
+                       acc_bits=b.pe_acc_bits, add_bits=b.pe_add_bits, name=b.name) for b in bundles]
         thr = min(os.cpu_count() or 1, 16)
         x0 = pool[0][0:1]
         got = forward_chain(pool[0], 0, torch.cuda.current_stream())[0:1].cpu().numpy()
@@ -192,8 +196,10 @@ def main():
         t1 = time.perf_counter()
         cur = xs
         for j, on in enumerate(onets):
-            cur = CO.forward(on, cur, threads=thr, want_f=False)["q_out"] if j == 0 else \
-                CO.forward_q(on, cur, threads=thr)["q_out"]
+            if j:       # float hand-off between chained nets: y = (q - zero_L) * f32(scale_L) of the upstream net
+                up = onets[j - 1]
+                cur = (cur.astype(np.float32) - np.float32(up.zero[up.L])) * np.float32(up.scale[up.L])
+            cur = CO.forward(on, cur, threads=thr, want_f=False)["q_out"]
         dt = time.perf_counter() - t1
         want = cur
         diff = got.astype(np.int32) - want.astype(np.int32)

@@ -230,8 +230,9 @@ struct StageNHWC16 {
 #endif
 #define SESRQ_TILE_WALK(STAGE_T, BUF0, BUF1, COMPUTE)                                              \
     {                                                                                               \
-        const int t_begin = blockIdx.y * a.chunk_tiles;                                             \
-        const int t_end = min(t_begin + a.chunk_tiles, (a.H + MTH - 1) / MTH);                      \
+        const int row_tiles_ = (a.H + MTH - 1) / MTH;      /* runs of (almost) equal length */      \
+        const int t_begin = (int)(((long long)blockIdx.y * row_tiles_) / gridDim.y);                \
+        const int t_end = (int)(((long long)(blockIdx.y + 1) * row_tiles_) / gridDim.y);            \
         STAGE_T st;                                                                                 \
         st.init(a, n_img, x0, tid);                                                                 \
         STAMP(0)                                                                                    \
@@ -724,7 +725,7 @@ static void launch(K kern, ConvArgs a, hipStream_t st) {
     long long k = (a.wg_budget > 0 ? (long long)a.wg_budget : (long long)blocks_per_cu * num_cu) / ((long long)strips * a.N);
     k = std::max(1LL, std::min<long long>(k, row_tiles));
     a.chunk_tiles = (int)((row_tiles + k - 1) / k);
-    dim3 grid(strips, (row_tiles + a.chunk_tiles - 1) / a.chunk_tiles, a.N);
+    dim3 grid(strips, (int)k, a.N);
     hipLaunchKernelGGL(kern, grid, dim3(256), 0, st, a);
 }
 

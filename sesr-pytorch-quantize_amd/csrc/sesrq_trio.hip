@@ -17,8 +17,9 @@
 // kernels pad (myQL/quan_func.py:351-356): the inner epilogues select the pad word there.
 // Only the merged accumulation mode (load-time proof: no 18-/20-bit clamp can fire) is fused; anything else
 // runs on the per-layer kernels.
+#include <stdlib.h>
+
 #include <algorithm>
-#include <map>
 #include <mutex>
 
 #include "sesrq_mfma_common.h"
@@ -31,6 +32,9 @@ constexpr int TH = 8;             // rows per step
 constexpr int TP = 66;            // LDS row pitch (pixels): computed columns -1 .. 64
 constexpr int TR = TH + 2;        // rows per LDS window
 constexpr int OOB = (int)0x80000000;
+constexpr int TRIO_WIN = TR * TP;          // pixels per LDS window; lane group 3 (zero weights) over-reads one pixel into whatever follows
+constexpr int TRIO_FRAGS = 3 * (3 * 64 + 4);   // per layer: 3 A fragments x 64 lanes + 4 add-constant words, 16 B each
+constexpr int TRIO_LDS_BYTES = (3 * TRIO_WIN + TRIO_FRAGS) * 16;       // 40 896 B: four workgroups per CU
 
 struct TrioStage {
     static constexpr int NIT = 3;         // 660 pixels (cold: 10 rows) or 528 (steady: 8 rows) over 256 threads
@@ -89,12 +93,15 @@ struct TrioEpiC {           // the field names the shared epilogues read
 
 template <int EPI_C>
 __global__ __launch_bounds__(256) void mfma_trio_kernel(const TrioArgs a) {
-    __shared__ int4 bufI[TR * TP + 2], bufA[TR * TP + 2], bufB[TR * TP + 2];      // + 2: lane group 3 over-reads one pixel
+    extern __shared__ int4 trio_lds[];             // dynamic: the launch pads the size so that exactly `occ` workgroups fit a CU
+    int4 *bufI = trio_lds, *bufA = trio_lds + TRIO_WIN, *bufB = trio_lds + 2 * TRIO_WIN, *frg = trio_lds + 3 * TRIO_WIN;
     const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, n = l & 15, g = l >> 4;
     const int n_img = blockIdx.z;
     const int x0 = blockIdx.x * TV - 2;              // frame column of computed column 0
+    // vertical runs of (almost) equal length: run c of n covers steps [c*S/n, (c+1)*S/n)
     const int steps_total = (a.H + TH - 1) / TH;
-    const int s_begin = blockIdx.y * a.chunk_steps, s_end = min(s_begin + a.chunk_steps, steps_total);
+    const int s_begin = (int)(((long long)blockIdx.y * steps_total) / gridDim.y);
+    const int s_end = (int)(((long long)(blockIdx.y + 1) * steps_total) / gridDim.y);
     if (s_begin >= s_end) return;
 
     const int c = 16 * w + n, gx = x0 + c;
@@ -103,13 +110,15 @@ __global__ __launch_bounds__(256) void mfma_trio_kernel(const TrioArgs a) {
     const int rdcol = c + g;                                       // window pixel of tap kx = g (window column = computed column + 1)
     const int wrcol = (c + 1) * 4 + g;                             // window dword of this lane's output word
 
-    v4i A[3][3], acc0[3];
+    // the weights live in LDS (9.4 KB), a phase reads its three A fragments and add constants from there: holding all three
+    // layers in registers (48 VGPRs) would cost the fourth wave per SIMD once the phases are software-pipelined
+    if (tid < 3 * 64 + 4) {
 #pragma unroll
-    for (int k = 0; k < 3; ++k) {
-        const int4 ac = a.l[k].afrag[g];
-        acc0[k] = (v4i){ac.x + MAGIC_I, ac.y + MAGIC_I, ac.z + MAGIC_I, ac.w + MAGIC_I};     // add constant + cvt-free requant bias
-#pragma unroll
-        for (int f = 0; f < 3; ++f) A[k][f] = ld_frag(a.l[k].afrag + 4 + f * 64 + l);
+        for (int k = 0; k < 3; ++k) {
+            int4 v = a.l[k].afrag[tid];                          // [0..3] add constants, [4..195] fragments
+            if (tid < 4) { v.x += MAGIC_I; v.y += MAGIC_I; v.z += MAGIC_I; v.w += MAGIC_I; }   // cvt-free requant bias
+            frg[k * (3 * 64 + 4) + tid] = v;
+        }
     }
     const size_t img = (size_t)a.H * a.W * 16;
     RowIO io;
@@ -120,47 +129,84 @@ __global__ __launch_bounds__(256) void mfma_trio_kernel(const TrioArgs a) {
     const int voff_c = col_out ? (g * a.W + gx) * 16 : OOB;       // + Y * row_bytes per step
     const TrioEpiC ec = {a.l[2].Mf, a.l[2].sh, a.l[2].z_next, a.Mres, a.shres, a.z_merge};
 
-    // inner layer K: window position 2+i <- positions i .. i+2 of the source window; row0 = frame row of i = 0
+    // inner layer K: window position 2+i <- positions i .. i+2 of the source window; row0 = frame row of i = 0.
+    // Rows go in groups of 4: the 12 MFMAs of a group (4 independent chains) are issued before the epilogues of the PREVIOUS
+    // group, so the matrix pipe works on group j+1 while the VALU requantises group j (written row by row, hipcc keeps one
+    // accumulator and serialises MFMA chain -> s_nop -> epilogue for every row).
     auto inner = [&](auto KC, auto I0, const int4 *src, int4 *dst, int row0) __attribute__((always_inline)) {
         constexpr int K = decltype(KC)::value, i0 = decltype(I0)::value;
+        constexpr int NG = (TH - i0 + 3) / 4;                   // groups of up to 4 rows
         const TrioLayer &L = a.l[K];
         const int4 *p = src + rdcol;
         unsigned *d = reinterpret_cast<unsigned *>(dst) + wrcol;
+        const int4 *fk = frg + K * (3 * 64 + 4);
+        const v4i acc0 = ld_frag(fk + g), A0 = ld_frag(fk + 4 + l), A1 = ld_frag(fk + 4 + 64 + l), A2 = ld_frag(fk + 4 + 128 + l);
         v4i B0 = ld_frag(p + (i0)*TP), B1 = ld_frag(p + (i0 + 1) * TP);
+        v4i acc[2][4];
+        auto chains = [&](int gi) __attribute__((always_inline)) {
 #pragma unroll
-        for (int i = i0; i < TH; ++i) {
-            const v4i B2 = ld_frag(p + (i + 2) * TP);
-            v4i acc = mfma(A[K][0], B0, acc0[K]);
-            acc = mfma(A[K][1], B1, acc);
-            acc = mfma(A[K][2], B2, acc);
-            B0 = B1; B1 = B2;
-            const int s[4] = {acc[0], acc[1], acc[2], acc[3]};
-            unsigned q = epi_mid<true>(s, L, L.zlo);
-            const int row = row0 + i;
-            const bool rok = (row >= 0) & (row < a.H);
-            q = (rok & col_in) ? q : (unsigned)L.pad_next;
-            d[(2 + i) * TP * 4] = q;
+            for (int r = 0; r < 4; ++r) {
+                const int i = i0 + 4 * gi + r;
+                if (i < TH) {
+                    const v4i B2 = ld_frag(p + (i + 2) * TP);
+                    v4i t = mfma(A0, B0, acc0);
+                    t = mfma(A1, B1, t);
+                    acc[gi & 1][r] = mfma(A2, B2, t);
+                    B0 = B1; B1 = B2;
+                }
+            }
+        };
+        auto finish = [&](int gi) __attribute__((always_inline)) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int i = i0 + 4 * gi + r;
+                if (i < TH) {
+                    const v4i t = acc[gi & 1][r];
+                    const int s[4] = {t[0], t[1], t[2], t[3]};
+                    unsigned q = epi_mid<true>(s, L, L.zlo);
+                    const int row = row0 + i;
+                    const bool rok = (row >= 0) & (row < a.H);
+                    q = (rok & col_in) ? q : (unsigned)L.pad_next;
+                    d[(2 + i) * TP * 4] = q;
+                }
+            }
+        };
+        chains(0);
+#pragma unroll
+        for (int gi = 0; gi < NG; ++gi) {
+            if (gi + 1 < NG) chains(gi + 1);
+            finish(gi);
         }
     };
-    // outer layer: output rows Y .. Y+7 from window positions 0 .. 9 of layer b
+    // outer layer: output rows Y .. Y+7 from window positions 0 .. 9 of layer b (same software pipeline: the MFMAs of the
+    // second group of 4 rows are issued before the epilogue + stores of the first)
     auto outer = [&](int Y) __attribute__((always_inline)) {
         const int4 *p = bufB + rdcol;
         io.voff = col_out ? voff_c + Y * io.row_bytes : OOB;
+        const int4 *fk = frg + 2 * (3 * 64 + 4);
+        const v4i acc0 = ld_frag(fk + g), A0 = ld_frag(fk + 4 + l), A1 = ld_frag(fk + 4 + 64 + l), A2 = ld_frag(fk + 4 + 128 + l);
         v4i B0 = ld_frag(p), B1 = ld_frag(p + TP);
-#pragma unroll
-        for (int y4 = 0; y4 < TH; y4 += 4) {
-            int s4[4][4];
+        v4i acc[2][4];
+        auto chains = [&](int gi) __attribute__((always_inline)) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const v4i B2 = ld_frag(p + (y4 + r + 2) * TP);
-                v4i acc = mfma(A[2][0], B0, acc0[2]);
-                acc = mfma(A[2][1], B1, acc);
-                acc = mfma(A[2][2], B2, acc);
+                const v4i B2 = ld_frag(p + (4 * gi + r + 2) * TP);
+                v4i t = mfma(A0, B0, acc0);
+                t = mfma(A1, B1, t);
+                acc[gi & 1][r] = mfma(A2, B2, t);
                 B0 = B1; B1 = B2;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) s4[r][i] = acc[i];
             }
-            emit_rows4<EPI_C, false, true>(s4, ec, io, y4, a.l[2].zlo);
+        };
+        chains(0);
+#pragma unroll
+        for (int gi = 0; gi < TH / 4; ++gi) {
+            if (gi + 1 < TH / 4) chains(gi + 1);
+            int s4[4][4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) s4[r][i] = acc[gi & 1][r][i];
+            emit_rows4<EPI_C, false, true>(s4, ec, io, 4 * gi, a.l[2].zlo);
         }
     };
     using std::integral_constant;
@@ -209,14 +255,15 @@ __global__ __launch_bounds__(256) void mfma_trio_kernel(const TrioArgs a) {
     }
 }
 
-// One round of workgroups that fits the chip (same sizing rule as the per-layer kernels, sesrq_mfma.hip): process-static
-// device properties, i.e. one process drives one device (the package's process-per-GPU model, sesrq/dist.py).
+// Launch geometry: the chip is filled EVENLY.  A workgroup lives for tens of microseconds here, so a compute unit that holds
+// one workgroup more than its neighbours sets the kernel time while the others idle (measured: 864 workgroups on 1024 slots,
+// SQ busy 1.47 x the average wave lifetime).  The dynamic LDS size is padded so that exactly `occ` workgroups fit a CU, and a
+// strip is cut into floor(occ * CUs / (strips * N)) runs whose lengths differ by at most one step.  Device properties are
+// process-static: one process drives one device (the package's process-per-GPU model, sesrq/dist.py).
 template <typename K>
 static void launch_trio_k(K kern, TrioArgs a, hipStream_t st) {
     static std::mutex mu;
-    static std::map<const void *, int> occ;
-    static int num_cu = 0;
-    int blocks_per_cu;
+    static int num_cu = 0, occ = 0;
     {
         std::lock_guard<std::mutex> lk(mu);
         if (!num_cu) {
@@ -224,21 +271,18 @@ static void launch_trio_k(K kern, TrioArgs a, hipStream_t st) {
             hipDeviceProp_t prop;
             if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) num_cu = prop.multiProcessorCount;
             if (num_cu < 1) num_cu = 256;
+            const char *e = getenv("SESRQ_TRIO_OCC");          // tuning knob (workgroups per CU): 3 or 4
+            occ = e ? atoi(e) : 4;
+            if (occ < 1 || occ > 5) occ = 4;
         }
-        auto it = occ.find((const void *)kern);
-        if (it == occ.end()) {
-            int b = 0;
-            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, kern, 256, 0) != hipSuccess || b < 1) b = 2;
-            it = occ.emplace((const void *)kern, b).first;
-        }
-        blocks_per_cu = it->second;
     }
+    const int lds = std::max(TRIO_LDS_BYTES, (160 * 1024 / occ) & ~1023);      // exactly occ workgroups per 160 KiB
     const int strips = (a.W + TV - 1) / TV, steps = (a.H + TH - 1) / TH;
-    long long k = (a.wg_budget > 0 ? (long long)a.wg_budget : (long long)blocks_per_cu * num_cu) / ((long long)strips * a.N);
+    long long k = (a.wg_budget > 0 ? (long long)a.wg_budget : (long long)occ * num_cu) / ((long long)strips * a.N);
     k = std::max(1LL, std::min<long long>(k, steps));
     a.chunk_steps = (int)((steps + k - 1) / k);
-    dim3 grid(strips, (steps + a.chunk_steps - 1) / a.chunk_steps, a.N);
-    hipLaunchKernelGGL(kern, grid, dim3(256), 0, st, a);
+    dim3 grid(strips, (int)k, a.N);
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, a);
 }
 
 int launch_trio(const TrioArgs &a, int epi_c, hipStream_t st) {

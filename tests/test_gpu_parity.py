@@ -308,6 +308,46 @@ def test_config5_shape_nrdm6_then_sesr_x2_chain():
     _cmp("nrdm_6 float output", y1, w1["y"])
     _cmp("chain int8 output", q2, w2["q_out"])
     assert tuple(q2.shape) == (2, 3, 90, 166)
+    # int8 hand-off: the second net takes the first one's int8 output and re-quantises it while staging
+    # (sesrq_options.i8_in_scale/zero) -- same bits as the fp32 hand-off, a quarter of the bytes, on both engines
+    q1, _ = e1.forward(torch.from_numpy(x).to(_dev()), want_f=False)
+    for kw in (dict(), dict(engine=_lib.ENGINE_DOT4)):
+        e2i = sesrq.Engine(bundle_from_oracle(sr), _dev(), upstream=bundle_from_oracle(nr), **kw)
+        q2i, _ = e2i.forward(q1)
+        _cmp("chain int8 hand-off", q2i, w2["q_out"])
+        # without the upstream domain an int8 frame is taken as q0 itself: a different result
+        assert not torch.equal(e2.forward(q1)[0], q2i)
+
+
+def test_config5_real_weights_nrdm6_then_sesr_x2_540p():
+    """BASELINE config 5 with the reference's own nrdm_6_G.pth: collapsed by this package (tests/golden/unpinned/
+    nrdm_6.collapsed.npz), calibrated by this package's Calibrator on rand_DM_Input_80x960 (nrdm_6.bundle.npz), chained into
+    the reference-calibrated SESR-x2 bundle, 960x540 -> 1920x1080, int8 hand-off.  PARITY UNPINNED: the reference cannot
+    int-simulate 8 convs nor the chain; this checks HIP vs the C oracle on the same bundle, full frame."""
+    from oracle import c_oracle as CO
+    from conftest import GOLDEN
+    from sesrq.bundle import Bundle
+    path = os.path.join(GOLDEN, "unpinned", "nrdm_6.bundle.npz")
+    if not os.path.isfile(path):
+        pytest.skip("nrdm_6.bundle.npz not generated yet (tools/make_nrdm6_bundle.py on the GPU box)")
+    b1 = Bundle.load(path)
+    assert b1.L == 8 and b1.pixel_shuffle == 1
+    fx, meta, sr, _ = fixture_case(os.path.join(GOLDEN, "sesr_x2_rand.crop.npz"))
+    b2 = bundle_from_oracle(sr)
+    e1 = sesrq.Engine(b1, _dev())
+    e2 = sesrq.Engine(b2, _dev(), upstream=b1)
+    assert e1.launch_plan() == [(0, 1), (1, 3), (4, 3), (7, 1)]
+    x = rand_frame((1, 3, 540, 960), 5)
+    q1, _ = e1.forward(torch.from_numpy(x).to(_dev()), want_f=False)
+    q2, _ = e2.forward(q1, want_f=False)
+    nr = O.Net(layers=[O.Layer(wq=l.wq, add_const=l.add_const, M=l.M, n=l.n, relu=l.relu) for l in b1.layers], scale=b1.scale,
+               zero=b1.zero, M_res=b1.M_res, n_res=b1.n_res, pixel_shuffle=1, name="nrdm_6")
+    w1 = CO.forward(nr, x, want_f=False)["q_out"]
+    _cmp("nrdm_6 540p int8 output", q1, w1)
+    y1 = (w1.astype(np.float32) - np.float32(b1.zero[8])) * np.float32(b1.scale[8])
+    w2 = CO.forward(sr, y1, want_f=False)["q_out"]
+    _cmp("chain output 1080p", q2, w2)
+    assert tuple(q2.shape) == (1, 3, 1080, 1920)
 
 
 @pytest.mark.parametrize("eng", ENGINES, ids=[e[0] for e in ENGINES])
