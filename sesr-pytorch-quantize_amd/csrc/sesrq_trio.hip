@@ -4,7 +4,7 @@
 // per-layer kernels (sesrq_mfma.hip), and no global staging / transpose / 16-byte store work for the two inner
 // layers (their MFMA results go to LDS as they come out: lane (n, g) owns word g of pixel n).
 //
-// Geometry: a workgroup (4 waves = 4 groups of 16 columns) owns a strip of TW = 64 COMPUTED columns of which
+// Geometry: a workgroup (4 waves = 4 groups of 16 columns) owns a strip of 64 COMPUTED columns of which
 // TV = 60 are valid outputs (a 3x3 layer eats one column per side; the two outermost computed columns of the
 // inner layers are never read by a valid output) and walks down it in steps of TH = 8 rows.  Three LDS
 // windows of TH + 2 rows each (IN, A, B; row pitch 66 pixels: columns -1 .. 64) hold
@@ -26,15 +26,13 @@
 
 namespace sesrq {
 
-constexpr int TW = 64;            // computed columns per strip
 constexpr int TV = 60;            // valid output columns per strip
 constexpr int TH = 8;             // rows per step
 constexpr int TP = 66;            // LDS row pitch (pixels): computed columns -1 .. 64
 constexpr int TR = TH + 2;        // rows per LDS window
 constexpr int OOB = (int)0x80000000;
-constexpr int TRIO_WIN = TR * TP;          // pixels per LDS window; lane group 3 (zero weights) over-reads one pixel into whatever follows
-constexpr int TRIO_FRAGS = 3 * (3 * 64 + 4);   // per layer: 3 A fragments x 64 lanes + 4 add-constant words, 16 B each
-constexpr int TRIO_LDS_BYTES = (3 * TRIO_WIN + TRIO_FRAGS) * 16;       // 40 896 B: four workgroups per CU
+constexpr int TRIO_WIN = TR * TP + 2;      // pixels per LDS window (+ 2: lane group 3 over-reads one pixel)
+constexpr int TRIO_LDS_BYTES = 3 * TRIO_WIN * 16;
 
 struct TrioStage {
     static constexpr int NIT = 3;         // 660 pixels (cold: 10 rows) or 528 (steady: 8 rows) over 256 threads
@@ -94,7 +92,7 @@ struct TrioEpiC {           // the field names the shared epilogues read
 template <int EPI_C>
 __global__ __launch_bounds__(256) void mfma_trio_kernel(const TrioArgs a) {
     extern __shared__ int4 trio_lds[];             // dynamic: the launch pads the size so that exactly `occ` workgroups fit a CU
-    int4 *bufI = trio_lds, *bufA = trio_lds + TRIO_WIN, *bufB = trio_lds + 2 * TRIO_WIN, *frg = trio_lds + 3 * TRIO_WIN;
+    int4 *bufI = trio_lds, *bufA = trio_lds + TRIO_WIN, *bufB = trio_lds + 2 * TRIO_WIN;
     const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, n = l & 15, g = l >> 4;
     const int n_img = blockIdx.z;
     const int x0 = blockIdx.x * TV - 2;              // frame column of computed column 0
@@ -110,15 +108,13 @@ __global__ __launch_bounds__(256) void mfma_trio_kernel(const TrioArgs a) {
     const int rdcol = c + g;                                       // window pixel of tap kx = g (window column = computed column + 1)
     const int wrcol = (c + 1) * 4 + g;                             // window dword of this lane's output word
 
-    // the weights live in LDS (9.4 KB), a phase reads its three A fragments and add constants from there: holding all three
-    // layers in registers (48 VGPRs) would cost the fourth wave per SIMD once the phases are software-pipelined
-    if (tid < 3 * 64 + 4) {
+    v4i A[3][3], acc0[3];
 #pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            int4 v = a.l[k].afrag[tid];                          // [0..3] add constants, [4..195] fragments
-            if (tid < 4) { v.x += MAGIC_I; v.y += MAGIC_I; v.z += MAGIC_I; v.w += MAGIC_I; }   // cvt-free requant bias
-            frg[k * (3 * 64 + 4) + tid] = v;
-        }
+    for (int k = 0; k < 3; ++k) {
+        const int4 ac = a.l[k].afrag[g];
+        acc0[k] = (v4i){ac.x + MAGIC_I, ac.y + MAGIC_I, ac.z + MAGIC_I, ac.w + MAGIC_I};     // add constant + cvt-free requant bias
+#pragma unroll
+        for (int f = 0; f < 3; ++f) A[k][f] = ld_frag(a.l[k].afrag + 4 + f * 64 + l);
     }
     const size_t img = (size_t)a.H * a.W * 16;
     RowIO io;
@@ -130,83 +126,50 @@ __global__ __launch_bounds__(256) void mfma_trio_kernel(const TrioArgs a) {
     const TrioEpiC ec = {a.l[2].Mf, a.l[2].sh, a.l[2].z_next, a.Mres, a.shres, a.z_merge};
 
     // inner layer K: window position 2+i <- positions i .. i+2 of the source window; row0 = frame row of i = 0.
-    // Rows go in groups of 4: the 12 MFMAs of a group (4 independent chains) are issued before the epilogues of the PREVIOUS
-    // group, so the matrix pipe works on group j+1 while the VALU requantises group j (written row by row, hipcc keeps one
-    // accumulator and serialises MFMA chain -> s_nop -> epilogue for every row).
+    // Written row by row: hipcc keeps ONE accumulator and serialises chain -> epilogue per row, the other three waves of the
+    // SIMD fill the gaps.  A hand-pipelined variant (MFMAs of the next 4 rows issued before the epilogues of the previous 4,
+    // weights in LDS to stay at 4 waves per SIMD) ran 11 % SLOWER alone (42 vs 38 us at 1080p) and the same with two frames in
+    // flight (same-box A/B, round 2): the instruction count is what bounds this kernel, not the order inside one wave.
     auto inner = [&](auto KC, auto I0, const int4 *src, int4 *dst, int row0) __attribute__((always_inline)) {
         constexpr int K = decltype(KC)::value, i0 = decltype(I0)::value;
-        constexpr int NG = (TH - i0 + 3) / 4;                   // groups of up to 4 rows
         const TrioLayer &L = a.l[K];
         const int4 *p = src + rdcol;
         unsigned *d = reinterpret_cast<unsigned *>(dst) + wrcol;
-        const int4 *fk = frg + K * (3 * 64 + 4);
-        const v4i acc0 = ld_frag(fk + g), A0 = ld_frag(fk + 4 + l), A1 = ld_frag(fk + 4 + 64 + l), A2 = ld_frag(fk + 4 + 128 + l);
         v4i B0 = ld_frag(p + (i0)*TP), B1 = ld_frag(p + (i0 + 1) * TP);
-        v4i acc[2][4];
-        auto chains = [&](int gi) __attribute__((always_inline)) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int i = i0 + 4 * gi + r;
-                if (i < TH) {
-                    const v4i B2 = ld_frag(p + (i + 2) * TP);
-                    v4i t = mfma(A0, B0, acc0);
-                    t = mfma(A1, B1, t);
-                    acc[gi & 1][r] = mfma(A2, B2, t);
-                    B0 = B1; B1 = B2;
-                }
-            }
-        };
-        auto finish = [&](int gi) __attribute__((always_inline)) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int i = i0 + 4 * gi + r;
-                if (i < TH) {
-                    const v4i t = acc[gi & 1][r];
-                    const int s[4] = {t[0], t[1], t[2], t[3]};
-                    unsigned q = epi_mid<true>(s, L, L.zlo);
-                    const int row = row0 + i;
-                    const bool rok = (row >= 0) & (row < a.H);
-                    q = (rok & col_in) ? q : (unsigned)L.pad_next;
-                    d[(2 + i) * TP * 4] = q;
-                }
-            }
-        };
-        chains(0);
-#pragma unroll
-        for (int gi = 0; gi < NG; ++gi) {
-            if (gi + 1 < NG) chains(gi + 1);
-            finish(gi);
+        for (int i = i0; i < TH; ++i) {
+            const v4i B2 = ld_frag(p + (i + 2) * TP);
+            v4i acc = mfma(A[K][0], B0, acc0[K]);
+            acc = mfma(A[K][1], B1, acc);
+            acc = mfma(A[K][2], B2, acc);
+            B0 = B1; B1 = B2;
+            const int s[4] = {acc[0], acc[1], acc[2], acc[3]};
+            unsigned q = epi_mid<true>(s, L, L.zlo);
+            const int row = row0 + i;
+            const bool rok = (row >= 0) & (row < a.H);
+            q = (rok & col_in) ? q : (unsigned)L.pad_next;
+            d[(2 + i) * TP * 4] = q;
         }
     };
-    // outer layer: output rows Y .. Y+7 from window positions 0 .. 9 of layer b (same software pipeline: the MFMAs of the
-    // second group of 4 rows are issued before the epilogue + stores of the first)
+    // outer layer: output rows Y .. Y+7 from window positions 0 .. 9 of layer b
     auto outer = [&](int Y) __attribute__((always_inline)) {
         const int4 *p = bufB + rdcol;
         io.voff = col_out ? voff_c + Y * io.row_bytes : OOB;
-        const int4 *fk = frg + 2 * (3 * 64 + 4);
-        const v4i acc0 = ld_frag(fk + g), A0 = ld_frag(fk + 4 + l), A1 = ld_frag(fk + 4 + 64 + l), A2 = ld_frag(fk + 4 + 128 + l);
         v4i B0 = ld_frag(p), B1 = ld_frag(p + TP);
-        v4i acc[2][4];
-        auto chains = [&](int gi) __attribute__((always_inline)) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const v4i B2 = ld_frag(p + (4 * gi + r + 2) * TP);
-                v4i t = mfma(A0, B0, acc0);
-                t = mfma(A1, B1, t);
-                acc[gi & 1][r] = mfma(A2, B2, t);
-                B0 = B1; B1 = B2;
-            }
-        };
-        chains(0);
-#pragma unroll
-        for (int gi = 0; gi < TH / 4; ++gi) {
-            if (gi + 1 < TH / 4) chains(gi + 1);
+        for (int y4 = 0; y4 < TH; y4 += 4) {
             int s4[4][4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
+            for (int r = 0; r < 4; ++r) {
+                const v4i B2 = ld_frag(p + (y4 + r + 2) * TP);
+                v4i acc = mfma(A[2][0], B0, acc0[2]);
+                acc = mfma(A[2][1], B1, acc);
+                acc = mfma(A[2][2], B2, acc);
+                B0 = B1; B1 = B2;
 #pragma unroll
-                for (int i = 0; i < 4; ++i) s4[r][i] = acc[gi & 1][r][i];
-            emit_rows4<EPI_C, false, true>(s4, ec, io, 4 * gi, a.l[2].zlo);
+                for (int i = 0; i < 4; ++i) s4[r][i] = acc[i];
+            }
+            emit_rows4<EPI_C, false, true>(s4, ec, io, y4, a.l[2].zlo);
         }
     };
     using std::integral_constant;
