@@ -80,17 +80,29 @@ struct LastStore {
         }
     }
     // gy: wave-uniform row; row_ok: false drops this lane's stores (lanes whose own row gy + lane_row is below the frame)
-    template <bool BIASED>
+    // FAST = 2 / 4: PixelShuffle factor known at compile time, int8 output only, every row valid (the call sites test the
+    // row): no output-kind / shuffle-factor branches and no per-row offset selects in the hot loop of the SESR last layer
+    template <bool BIASED, int FAST = 0>
     __device__ __forceinline__ void store(const int s[4], const ConvArgs &a, int gy, float zlo, bool row_ok = true) const {
-        int vo[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) vo[i] = row_ok ? this->vo[i] : (int)0x10000000;
         v2f v01, v23;
         requant4<BIASED>(s, a.Mf, a.sh, a.z_out, v01, v23);
         const v2f mg = {MAGIC, MAGIC};
         v2f c01 = {med3(v01[0], zlo, 127.f), med3(v01[1], zlo, 127.f)}, c23 = {med3(v23[0], zlo, 127.f), med3(v23[1], zlo, 127.f)};
         c01 = c01 + mg; c23 = c23 + mg;                    // low mantissa bits = rint(value), two's complement
         const int so = gy * row_elems;
+        if constexpr (FAST != 0) {
+            const unsigned w = pack_lo_bytes(fbits(c01[0]), fbits(c01[1]), fbits(c23[0]), fbits(c23[1]));
+            if constexpr (FAST == 2) {
+                __builtin_amdgcn_raw_buffer_store_b16((unsigned short)(w & 0xffffu), rq, this->vo[0], so, 0);
+                __builtin_amdgcn_raw_buffer_store_b16((unsigned short)(w >> 16), rq, this->vo[2], so, 0);
+            } else {
+                __builtin_amdgcn_raw_buffer_store_b32(w, rq, this->vo[0], so, 0);
+            }
+            return;
+        }
+        int vo[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) vo[i] = row_ok ? this->vo[i] : (int)0x10000000;
         if (a.out_q) {
             const unsigned w = pack_lo_bytes(fbits(c01[0]), fbits(c01[1]), fbits(c23[0]), fbits(c23[1]));
             if (r == 2) {
@@ -228,23 +240,24 @@ struct StageNHWC16 {
 #else
 #define STAMP(k)
 #endif
-#define SESRQ_TILE_WALK(STAGE_T, BUF0, BUF1, COMPUTE)                                              \
+#define SESRQ_TILE_WALK(STAGE_T, BUF0, BUF1, COMPUTE) SESRQ_TILE_WALK_H(MTH, STAGE_T, BUF0, BUF1, COMPUTE)
+#define SESRQ_TILE_WALK_H(TILE_H, STAGE_T, BUF0, BUF1, COMPUTE)                                              \
     {                                                                                               \
-        const int row_tiles_ = (a.H + MTH - 1) / MTH;      /* runs of (almost) equal length */      \
+        const int row_tiles_ = (a.H + (TILE_H) - 1) / (TILE_H);      /* runs of (almost) equal length */      \
         const int t_begin = (int)(((long long)blockIdx.y * row_tiles_) / gridDim.y);                \
         const int t_end = (int)(((long long)(blockIdx.y + 1) * row_tiles_) / gridDim.y);            \
         STAGE_T st;                                                                                 \
         st.init(a, n_img, x0, tid);                                                                 \
         STAMP(0)                                                                                    \
-        st.load_first(a, n_img, x0, t_begin * MTH, tid);                                            \
+        st.load_first(a, n_img, x0, t_begin * (TILE_H), tid);                                            \
         STAMP(1)                                                                                    \
         st.store(BUF0, a, tid);                                                                     \
         __syncthreads();                                                                            \
         STAMP(2)                                                                                    \
         for (int t = t_begin; t < t_end; ++t) {                                                     \
-            const int y0 = t * MTH;                                                                 \
+            const int y0 = t * (TILE_H);                                                                 \
             const bool cur0 = ((t - t_begin) & 1) == 0;                                             \
-            if (t + 1 < t_end) st.load(a, n_img, x0, y0 + MTH, tid);                                \
+            if (t + 1 < t_end) st.load(a, n_img, x0, y0 + (TILE_H), tid);                                \
             { const int4 *cur_tile = cur0 ? BUF0 : BUF1; COMPUTE(cur_tile) }                        \
             STAMP(3 + 3 * (t - t_begin))                                                            \
             if (t + 1 < t_end) { if (cur0) st.store(BUF1, a, tid); else st.store(BUF0, a, tid); }  \
@@ -333,7 +346,8 @@ __global__ __launch_bounds__(256) void mfma_h3_kernel(const ConvArgs a) {
 }
 
 // ------------------------------------------------------------------ 5x5, 16 input channels
-template <int MODE, int EPI>
+// FAST (EPI_LAST only): 2 / 4 = PixelShuffle factor, int8 output only (LastStore::store); 0 = every output kind
+template <int MODE, int EPI, int FAST = 0>
 __global__ __launch_bounds__(256) void mfma_h5_kernel(const ConvArgs a) {
     constexpr bool GENERAL = MODE == GEN_STD || MODE == GEN_ANY;
     constexpr int SW = MTW + 8;          // 2 + 64 + 2 halo, + over-read of the kx = 4..7 group
@@ -402,7 +416,7 @@ __global__ __launch_bounds__(256) void mfma_h5_kernel(const ConvArgs a) {
                     }
                     finish_sums<MODE>(s4[r], acc, ac, a);
                     if constexpr (EPI == EPI_LAST) {
-                        if (y0 + y < a.H) ls.store<BIASED>(s4[r], a, y0 + y, zlo);
+                        if (y0 + y < a.H) ls.store<BIASED, FAST>(s4[r], a, y0 + y, zlo);
                     }
                 }
                 if constexpr (EPI != EPI_LAST) emit_rows4<EPI, false, BIASED>(s4, a, io, y4, zlo);
@@ -430,7 +444,7 @@ __global__ __launch_bounds__(256) void mfma_h5_kernel(const ConvArgs a) {
                     }
                     finish_sums<MODE>(s4[r], acc, ac, a);
                     if constexpr (EPI == EPI_LAST) {
-                        if (y0 + y < a.H) ls.store<BIASED>(s4[r], a, y0 + y, zlo);
+                        if (y0 + y < a.H) ls.store<BIASED, FAST>(s4[r], a, y0 + y, zlo);
                     }
                 }
                 if constexpr (EPI != EPI_LAST) emit_rows4<EPI, false, BIASED>(s4, a, io, y4, zlo);
@@ -599,7 +613,11 @@ struct StageFrame {
     }
 };
 
-constexpr int F5_SH = MTH + 4;
+#ifndef SESRQ_F5_TH
+#define SESRQ_F5_TH 12     /* 12 rows: 8 is 1.3 us faster alone (shorter prologue), 12 and 16 re-quantise fewer halo pixels; with two frames in flight 12 gave +1 % (same-box A/B, round 2) */
+#endif
+constexpr int F5_TH = SESRQ_F5_TH;      // first-layer tile height (rows)
+constexpr int F5_SH = F5_TH + 4;
 constexpr int F5_SWP = MTW + 8;         // staged pixel columns (2 halo + 64 + 2 halo + over-read)
 constexpr int F5_PITCH = F5_SWP + 8;    // LDS row pitch in pixels: 16 dwords mod 32, so the four lane groups of an
                                         // operand read (rows g, g+1, ...) hit disjoint banks
@@ -639,7 +657,7 @@ __device__ __forceinline__ void mfma_f5_body(const ConvArgs &a, int4 *buf0, int4
         const RowIO io = make_rowio(a, n_img, y0, gx, g);
         const int *cpw = reinterpret_cast<const int *>(cp);
 #pragma unroll 1
-        for (int y4 = 0; y4 < MTH; y4 += 4) {
+        for (int y4 = 0; y4 < F5_TH; y4 += 4) {
             int s4[4][4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -670,7 +688,7 @@ __device__ __forceinline__ void mfma_f5_body(const ConvArgs &a, int4 *buf0, int4
     };
 #define SESRQ_COMPUTE(B) compute(B, y0);
     using Stage = StageFrame<SRC, SH, SWP, PITCH>;
-    SESRQ_TILE_WALK(Stage, buf0, buf1, SESRQ_COMPUTE)
+    SESRQ_TILE_WALK_H(F5_TH, Stage, buf0, buf1, SESRQ_COMPUTE)
 #undef SESRQ_COMPUTE
 }
 // 4 waves per SIMD for the merged / hybrid first layer: with the default heuristics hipcc takes 141-153 VGPRs here (3 waves);
@@ -700,7 +718,7 @@ extern "C" int sesrq_debug_fetch_stamps(void *host, size_t bytes) {
 // lot between the merged and general variants); a strip's row tiles are then cut into the largest
 // number of equal vertical runs that still fits.
 template <typename K>
-static void launch(K kern, ConvArgs a, hipStream_t st) {
+static void launch(K kern, ConvArgs a, hipStream_t st, int tile_h = MTH) {
     static std::mutex mu;
     static std::map<const void *, int> occ;          // per kernel (all instantiations share this function type)
     static int num_cu = 0;
@@ -721,7 +739,7 @@ static void launch(K kern, ConvArgs a, hipStream_t st) {
         }
         blocks_per_cu = it->second;
     }
-    const int strips = (a.W + MTW - 1) / MTW, row_tiles = (a.H + MTH - 1) / MTH;
+    const int strips = (a.W + MTW - 1) / MTW, row_tiles = (a.H + tile_h - 1) / tile_h;
     long long k = (a.wg_budget > 0 ? (long long)a.wg_budget : (long long)blocks_per_cu * num_cu) / ((long long)strips * a.N);
     k = std::max(1LL, std::min<long long>(k, row_tiles));
     a.chunk_tiles = (int)((row_tiles + k - 1) / k);
@@ -761,15 +779,17 @@ int launch_mfma(const LayerPlan &lp, const ConvArgs &a_in, int src, int epi, boo
             }
             if (epi == EPI_MID) SESRQ_BY_MODE(mfma_h5_kernel, EPI_MID);
             else if (epi == EPI_PRERES) SESRQ_BY_MODE(mfma_h5_kernel, EPI_PRERES);
+            else if (a.out_q && !a.out_f && a.ps == 2) SESRQ_BY_MODE(mfma_h5_kernel, EPI_LAST, 2);
+            else if (a.out_q && !a.out_f && a.ps == 4) SESRQ_BY_MODE(mfma_h5_kernel, EPI_LAST, 4);
             else SESRQ_BY_MODE(mfma_h5_kernel, EPI_LAST);
             break;
         case MFMA_F5:
 #define SESRQ_F5(...)                                                                    \
     do {                                                                                 \
-        if (mode == MERGED) launch(mfma_f5_kernel_w4<MERGED, __VA_ARGS__>, a, st);       \
-        else if (mode == HYB) launch(mfma_f5_kernel_w4<HYB, __VA_ARGS__>, a, st);        \
-        else if (mode == GEN_STD) launch(mfma_f5_kernel<GEN_STD, __VA_ARGS__>, a, st);   \
-        else launch(mfma_f5_kernel<GEN_ANY, __VA_ARGS__>, a, st);                        \
+        if (mode == MERGED) launch(mfma_f5_kernel_w4<MERGED, __VA_ARGS__>, a, st, F5_TH);       \
+        else if (mode == HYB) launch(mfma_f5_kernel_w4<HYB, __VA_ARGS__>, a, st, F5_TH);        \
+        else if (mode == GEN_STD) launch(mfma_f5_kernel<GEN_STD, __VA_ARGS__>, a, st, F5_TH);   \
+        else launch(mfma_f5_kernel<GEN_ANY, __VA_ARGS__>, a, st, F5_TH);                        \
     } while (0)
             if (src == SRC_F32) { if (a.rc_out) SESRQ_F5(SRC_F32, true); else SESRQ_F5(SRC_F32, false); }
             else if (src == SRC_I8D) { if (a.rc_out) SESRQ_F5(SRC_I8D, true); else SESRQ_F5(SRC_I8D, false); }

@@ -166,6 +166,11 @@ class SesrqGraphModule(torch.fx.GraphModule):
     def sesrq_bundle(self) -> Bundle:
         return lower(self)
 
+    def sesrq_lowered(self, device) -> torch.fx.GraphModule:
+        """The spliced graph collapsed to ONE operator node: input -> torch.ops.sesrq.forward -> float output."""
+        from .torch_op import lowered_module
+        return lowered_module(self._sesrq_engine(device))
+
     def recompile(self):
         # GraphModule installs the generated python forward on the per-instance class; put the fused
         # device forward back on top of it (the generated code stays available as `self.code`).
@@ -193,7 +198,9 @@ class SesrqGraphModule(torch.fx.GraphModule):
                 STORE[f"input/input.{k}.scale"] = cal.last_scale[k]
                 STORE[f"input/input.{k}.zero"] = cal.last_zero[k]
             return y
+        from . import torch_op
         eng = self._sesrq_engine(x.device)
-        q, y = eng.forward(x.float() if x.dtype != torch.int8 else x)
+        eid = getattr(eng, "_op_id", None) or torch_op.register_engine(eng)
+        q, y = torch.ops.sesrq.forward(x.float() if x.dtype != torch.int8 else x, eid)     # the registered operator
         self.__dict__["last_q"] = q
         return y

@@ -218,3 +218,40 @@ def test_reference_float_checkpoint_gives_the_golden_int8_weights(ckpt, mflag, c
     b = model.sesrq_bundle()
     for k in range(5):
         np.testing.assert_array_equal(b.layers[k].wq, fx[f"Wq{k}"])
+
+
+def test_registered_torch_op_schema_and_fake_kernel():
+    """torch.ops.sesrq.forward is a registered operator: schema, shape inference through the fake kernel, one op
+    node in the lowered graph; no CPU kernel (the product path never falls back)."""
+    from sesrq import torch_op
+
+    class FakeEngine:                       # only what the fake kernel and the graph builder touch
+        def out_shape(self, N, H, W):
+            return (N, 3, 2 * H, 2 * W)
+    eng = FakeEngine()
+    eid = torch_op.register_engine(eng)
+    assert str(torch.ops.sesrq.forward.default._schema) == "sesrq::forward(Tensor x, SymInt engine_id) -> (Tensor, Tensor)" or \
+        "sesrq::forward(Tensor x, int engine_id) -> (Tensor, Tensor)" in str(torch.ops.sesrq.forward.default._schema)
+    from torch._subclasses.fake_tensor import FakeTensorMode
+    with FakeTensorMode():
+        q, y = torch.ops.sesrq.forward(torch.empty(2, 3, 10, 12), eid)
+        assert tuple(q.shape) == (2, 3, 20, 24) and q.dtype == torch.int8 and y.dtype == torch.float32
+    gm = torch_op.lowered_module(eng)
+    ops = [n for n in gm.graph.nodes if n.op == "call_function" and n.target is torch.ops.sesrq.forward.default]
+    assert len(ops) == 1 and len([n for n in gm.graph.nodes if n.op == "call_function"]) == 2      # the op + getitem
+    with pytest.raises((NotImplementedError, RuntimeError)):
+        torch.ops.sesrq.forward(torch.zeros(1, 3, 4, 4), eid)                 # CPU tensor: no kernel
+    with pytest.raises(RuntimeError, match="not registered"):
+        torch_op._engine(10 ** 9)
+
+
+@pytest.mark.gpu
+def test_lowered_one_op_graph_is_the_golden_output():
+    STORE.clear()
+    model = sim.splice(sim.float_model(5, params=os.path.join(GOLDEN, "sesr_x4.params.npz")))
+    fx, meta = load_fixture(os.path.join(GOLDEN, "sesr_x4.crop.npz"))
+    x = torch.from_numpy(fx["x"]).cuda()
+    gm = model.sesrq_lowered(x.device)
+    assert [n.target for n in gm.graph.nodes if n.op == "call_function"][0] is torch.ops.sesrq.forward.default
+    np.testing.assert_array_equal(gm(x).cpu().numpy(), fx["out"])
+    np.testing.assert_array_equal(model(x).cpu().numpy(), fx["out"])
