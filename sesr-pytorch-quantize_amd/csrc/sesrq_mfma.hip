@@ -39,7 +39,10 @@
 namespace sesrq {
 
 constexpr int MTW = 64;   // tile width : 4 waves x 16 pixels
-constexpr int MTH = 8;    // tile height: rows walked by every wave (multiple of 4); 8 beats 12 and 16 on 1080p (latency hiding vs halo)
+#ifndef SESRQ_MTH
+#define SESRQ_MTH 8
+#endif
+constexpr int MTH = SESRQ_MTH;    // tile height: rows walked by every wave (multiple of 4); 8 beats 12 and 16 on 1080p (latency hiding vs halo)
 
 // last layer: requantise into the output domain + PixelShuffle(r) store (int8 and/or fp32).
 // A lane owns output slots o = 4g..4g+3 of pixel (gy, gx); everything that depends only on the lane

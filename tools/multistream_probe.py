@@ -5,8 +5,8 @@ from sesrq import _lib
 from sesrq.bundle import Bundle
 b = Bundle.load("tests/golden/sesr_x2_rand.crop.npz")
 dev = torch.device("cuda:0")
-for engname, eng in (("mfma", _lib.ENGINE_MFMA), ("fused", _lib.ENGINE_FUSED)):
-    e = sesrq.Engine(b, dev, engine=eng)
+for engname, kw in (("trio", dict()), ("per-layer", dict(fuse_hidden=False))):
+    e = sesrq.Engine(b, dev, engine=_lib.ENGINE_MFMA, **kw)
     x = torch.rand(1, 3, 1080, 1920, device=dev)
     for NS in (1, 2, 3, 4, 6):
         streams = [torch.cuda.Stream() for _ in range(NS)]

@@ -1,0 +1,70 @@
+#!/usr/bin/env python3
+"""Merge the rocprofv3 PMC passes of tools/profile_round.sh into <dir>/pmc_summary.json (bench.py reads the committed copy,
+profiles/pmc_summary.json) and a markdown table <dir>/sq_counters.md.  Per-launch averages over the bench kernels.
+HBM bytes per launch = 2 x FETCH_SIZE + WRITE_SIZE (KiB -> bytes): FETCH_SIZE reports half of the bytes of 16-B/lane streaming
+reads on gfx950, WRITE_SIZE is exact for 16-B/lane stores (/opt/skills/guides/MI355X_MICROARCH.md, HBM); narrower stores
+(the 2-byte PixelShuffle runs of the last layer) are uncalibrated and flagged."""
+import collections
+import csv
+import glob
+import json
+import os
+import sys
+
+root = sys.argv[1]
+N_SIMD, N_SE = 1024, 32
+agg = collections.defaultdict(lambda: collections.defaultdict(list))
+for f in glob.glob(os.path.join(root, "pmc_*", "**", "*counter_collection.csv"), recursive=True):
+    for r in csv.DictReader(open(f)):
+        k = r["Kernel_Name"]
+        if "sesrq" not in k or "verify" in k:
+            continue
+        agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+order = ["mfma_f5", "mfma_trio", "mfma_h3", "mfma_h5"]
+
+
+def launch_key(k):
+    for i, o in enumerate(order):
+        if o in k:
+            return i
+    return 99
+
+
+kernels = sorted(agg, key=launch_key)
+rows, summary = [], {}
+for li, k in enumerate(kernels):
+    c = {n: sum(v) / len(v) for n, v in agg[k].items()}
+    cyc = c.get("SQ_BUSY_CYCLES", 0) / N_SE                      # kernel length in cycles (SQ busy, per SE)
+    ent = {"kernel": k.split("(")[0]}
+    if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+        # the x2 correction holds for 16-B/lane streaming reads (NHWC16 activations: trio, h3, h5 kernels); the first layer
+        # reads the fp32 planes one dword per lane -- uncalibrated in the guide; counted as reported (1.1 x its input bytes)
+        wide = "mfma_f5" not in k
+        ent["fetch_bytes"] = (2 if wide else 1) * c["FETCH_SIZE"] * 1024
+        ent["fetch_correction"] = "x2 (16 B/lane loads)" if wide else "x1 (4 B/lane loads, uncalibrated)"
+        ent["write_bytes"] = c["WRITE_SIZE"] * 1024
+        ent["hbm_bytes_per_launch"] = round(ent["fetch_bytes"] + ent["write_bytes"])
+    if cyc:
+        ent["kernel_cycles"] = round(cyc)
+        ent["valu_util"] = round(c.get("SQ_ACTIVE_INST_VALU", 0) * 4 / N_SIMD / cyc, 3)
+        ent["mfma_util"] = round(c.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) / N_SIMD / cyc, 3)
+        ent["lds_util"] = round(c.get("SQ_LDS_IDX_ACTIVE", 0) / 256 / cyc, 3)
+        if c.get("SQ_WAVES"):
+            ent["wave_lifetime_cycles"] = round(c.get("SQ_WAVE_CYCLES", 0) * 4 / c["SQ_WAVES"])
+    if "GRBM_GUI_ACTIVE" in c:
+        ent["grbm_gui_active"] = round(c["GRBM_GUI_ACTIVE"])
+    ent["counters"] = {n: round(v) for n, v in sorted(c.items())}
+    summary[k] = ent
+    rows.append((k, c))
+json.dump(summary, open(os.path.join(root, "pmc_raw.json"), "w"), indent=1)
+names = sorted({n for _, c in rows for n in c})
+with open(os.path.join(root, "sq_counters.md"), "w") as f:
+    f.write("| counter (per launch) | " + " | ".join(k.split("(")[0].replace("void sesrq::", "") for k, _ in rows) + " |\n")
+    f.write("|---|" + "---|" * len(rows) + "\n")
+    for n in names:
+        f.write(f"| {n} | " + " | ".join(f"{c.get(n, float('nan')):.4g}" for _, c in rows) + " |\n")
+    for key in ("kernel_cycles", "valu_util", "mfma_util", "lds_util", "wave_lifetime_cycles", "hbm_bytes_per_launch"):
+        f.write(f"| **{key}** | " + " | ".join(str(summary[k].get(key, "")) for k, _ in rows) + " |\n")
+for k in kernels:
+    e = summary[k]
+    print(e["kernel"], {x: e.get(x) for x in ("hbm_bytes_per_launch", "kernel_cycles", "valu_util", "mfma_util", "lds_util", "wave_lifetime_cycles")})

@@ -7,7 +7,7 @@ import sesrq
 from sesrq import _lib
 from sesrq.bundle import Bundle
 b = Bundle.load(os.path.join(ROOT, "tests/golden/sesr_x2_rand.crop.npz"))
-e = sesrq.Engine(b, torch.device("cuda:0"), engine=_lib.ENGINE_MFMA)
+e = sesrq.Engine(b, torch.device("cuda:0"), engine=_lib.ENGINE_MFMA, fuse_hidden=False)   # stamps live in the per-layer kernels
 x = torch.rand(1, 3, 1080, 1920, device="cuda")
 for _ in range(5): e.forward(x)
 torch.cuda.synchronize()
