@@ -10,8 +10,9 @@ the pixel-shuffle store) over one batch of synthetic frames already resident in 
 BASELINE.json configs[1]: SESR-x2 INT8 1080p -> 4K, one frame per step; the steps rotate over 8 distinct resident
 input frames.  Frames shard across ranks with no data-path collective.  Rank 0 prints ONE JSON line.
 
-The timed region is `--repeats` blocks (default 5) of exactly K steps, each bracketed by synchronize + barrier on
-both sides; `value` is the MEDIAN block (min / max in `spread`), MAX over ranks per block (sesrq/dist.py:run_timed).
+The timed region is `--repeats` blocks (default: max(5, ceil(1500 / K))) of exactly K steps, each bracketed by
+synchronize + barrier on both sides; `value` is the MEDIAN block (min / max in `spread`, every block in `blocks_fps`),
+MAX over ranks per block (sesrq/dist.py:run_timed).
 """
 import argparse
 import json
@@ -68,7 +69,11 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--repeats", type=int, default=5, help="timed blocks of --steps steps; value = median block")
+    ap.add_argument("--repeats", type=int, default=0,
+                    help="timed blocks of exactly --steps steps each; value = the MEDIAN block.  0 = auto: max(5, ceil(1500 / steps)) "
+                         "blocks, i.e. at least ~0.1 s of timed work -- at the onset of load the chip's clock dips for 10-20 ms "
+                         "(blocks_fps shows it: 12.2, 10.5, 10.3, 10.9, 11.7 ... 12.5 k frames/s for 20-step blocks), so five "
+                         "20-step blocks (9 ms in all) would sit entirely inside that transient")
     ap.add_argument("--batch", type=int, default=0, help="frames per step per GPU (0 = the workload's own)")
     ap.add_argument("--streams", type=int, default=2,
                     help="HIP streams the steps are enqueued on round-robin (frames are independent; each stream has "
@@ -77,10 +82,14 @@ def main():
     ap.add_argument("--engine", default="auto", choices=["auto", "dot4", "mfma"])
     ap.add_argument("--no-fuse", action="store_true", help="one launch per layer (no fused hidden trio)")
     ap.add_argument("--wg-budget", type=int, default=0)
+    ap.add_argument("--timing-iters", type=int, default=200, help="forwards of the per-launch HIP-event timing (roofline)")
+    ap.add_argument("--blocking-sync", action="store_true", help="fence with the blocking torch.cuda.synchronize() only")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-e2e", action="store_true")
     args = ap.parse_args()
 
+    if args.repeats <= 0:
+        args.repeats = max(5, -(-1500 // max(1, args.steps)))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus > 1 and world == 1:
         # not launched by torchrun: start the ranks as children (before anything touches the GPU)
@@ -130,9 +139,10 @@ def main():
     counter = [0]
 
     def forward_chain(x, slot, stream):
+        # persistent pre-allocated buffers, streams fenced by run_timed: the engine's per-call stream bookkeeping is skipped
         cur = x
         for j, e in enumerate(engines):
-            e.forward(cur, want_q=True, want_f=False, out_q=outs[slot][j], stream=stream, slot=slot)
+            e.forward(cur, want_q=True, want_f=False, out_q=outs[slot][j], stream=stream, slot=slot, assume_ordered=True)
             cur = outs[slot][j]
         return cur
 
@@ -142,7 +152,59 @@ def main():
         if B > 0:
             forward_chain(pool[i % POOL], i % NS, streams[i % NS])
 
-    res = run_timed(grp, step, args.steps, args.warmup, repeats=args.repeats, sync=torch.cuda.synchronize, units_per_step=B)
+    # ---- before the timed region (rank 0): parity of a whole frame against the C oracle (doubles as the CPU baseline), then
+    # the per-launch HIP-event timing -- the device is busy and at its working clock when the timed blocks start
+    parity = cpu = launch_ms = fwd_ms = None
+    if rank == 0:
+        # ---- parity: the WHOLE first frame of the pool against the C oracle (checker only), which doubles as the CPU baseline
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        from oracle import sesrq_oracle as O, c_oracle as CO
+        onets = [O.Net(layers=[O.Layer(wq=l.wq, add_const=l.add_const, M=l.M, n=l.n, relu=l.relu) for l in b.layers],
+                       scale=b.scale, zero=b.zero, M_res=b.M_res, n_res=b.n_res, pixel_shuffle=b.pixel_shuffle, pe=b.pe_num,
+                       acc_bits=b.pe_acc_bits, add_bits=b.pe_add_bits, name=b.name) for b in bundles]
+        thr = min(os.cpu_count() or 1, 16)
+        x0 = pool[0][0:1]
+        got = forward_chain(pool[0], 0, torch.cuda.current_stream(dev))[0:1].cpu().numpy()
+        torch.cuda.synchronize()
+        xs = x0.cpu().numpy()
+        CO.forward(onets[0], xs[:, :, :64, :64], threads=thr, want_f=False)       # warm the thread pool
+        t1 = time.perf_counter()
+        cur = xs
+        for j, on in enumerate(onets):
+            if j:       # float hand-off between chained nets: y = (q - zero_L) * f32(scale_L) of the upstream net
+                up = onets[j - 1]
+                cur = (cur.astype(np.float32) - np.float32(up.zero[up.L])) * np.float32(up.scale[up.L])
+            cur = CO.forward(on, cur, threads=thr, want_f=False)["q_out"]
+        dt = time.perf_counter() - t1
+        want = cur
+        diff = got.astype(np.int32) - want.astype(np.int32)
+        maxdiff = int(np.abs(diff).max())
+        parity = {"checked": f"full frame ({'x'.join(map(str, got.shape))}) of pool frame 0 vs C oracle", "max_abs_diff_int8": maxdiff,
+                  "mismatches": int((diff != 0).sum()),
+                  "psnr_db": "inf" if maxdiff == 0 else float(10 * np.log10(255.0 ** 2 / np.mean(diff.astype(np.float64) ** 2)))}
+        cpu = None
+        if world == 1 and not args.no_cpu_baseline:
+            cpu = {"value": round(1.0 / dt, 4), "unit": "frames/s", "cores": thr, "kind": "port",
+                   "sample": f"1 frame {H}x{W} of the same workload through oracle/sesrq_oracle.c (OpenMP, {thr} threads), {dt:.2f} s "
+                             "(the same run is the parity reference)"}
+
+        # 200 forwards with an event pair around every launch (~20 ms): enough samples for the per-launch averages whatever
+        # --steps is, and the device is at its working clock when the timed blocks start right after
+        launch_ms, fwd_ms = engines[0].forward_timed(pool[0], iters=args.timing_iters)
+    fence_events = [torch.cuda.Event() for _ in streams]
+
+    def drain():
+        """Local drain of the fence: spin on one event per stream, then torch.cuda.synchronize().  The blocking wait alone
+        adds its host wake-up latency (~0.1-0.3 ms here) to every timed block -- 10-15 % of a 20-step block; the spin sees
+        the end of the device work within microseconds and the synchronize that follows returns at once."""
+        if not args.blocking_sync:
+            for e, st in zip(fence_events, streams):
+                e.record(st)
+            while not all(e.query() for e in fence_events):
+                pass
+        torch.cuda.synchronize()
+
+    res = run_timed(grp, step, args.steps, args.warmup, repeats=args.repeats, sync=drain, units_per_step=B)
     elapsed_med = statistics.median(res["elapsed"])
 
     result = None
@@ -153,7 +215,6 @@ def main():
         # ---- roofline per launch: HIP events on the launch stream, inside this process (first net of a chain)
         eng, bundle = engines[0], bundles[0]
         plan = eng.launch_plan()
-        launch_ms, fwd_ms = eng.forward_timed(pool[0], iters=max(10, min(50, args.steps)))
         alg = [launch_bytes_per_px(bundle, f, c, True) * px for f, c in plan]
         names = eng.layer_engines()
         kdom = int(np.argmax(launch_ms))
@@ -181,38 +242,6 @@ def main():
                             "launch must move (DESIGN 4.4; a fused trio moves 48 B/px, not its layers' 112); layerwise_frac = SURVEY "
                             "8(d)'s layer-by-layer bytes per frame x frames/s/GPU / peak = the north star's HBM-roofline fraction"}
 
-        # ---- parity: the WHOLE first frame of the pool against the C oracle (checker only), which doubles as the CPU baseline
-        sys.path.insert(0, os.path.join(ROOT, "tests"))
-        from oracle import sesrq_oracle as O, c_oracle as CO
-        onets = [O.Net(layers=[O.Layer(wq=l.wq, add_const=l.add_const, M=l.M, n=l.n, relu=l.relu) for l in b.layers],
-                       scale=b.scale, zero=b.zero, M_res=b.M_res, n_res=b.n_res, pixel_shuffle=b.pixel_shuffle, pe=b.pe_num,
-                       acc_bits=b.pe_acc_bits, add_bits=b.pe_add_bits, name=b.name) for b in bundles]
-        thr = min(os.cpu_count() or 1, 16)
-        x0 = pool[0][0:1]
-        got = forward_chain(pool[0], 0, torch.cuda.current_stream())[0:1].cpu().numpy()
-        torch.cuda.synchronize()
-        xs = x0.cpu().numpy()
-        CO.forward(onets[0], xs[:, :, :64, :64], threads=thr, want_f=False)       # warm the thread pool
-        t1 = time.perf_counter()
-        cur = xs
-        for j, on in enumerate(onets):
-            if j:       # float hand-off between chained nets: y = (q - zero_L) * f32(scale_L) of the upstream net
-                up = onets[j - 1]
-                cur = (cur.astype(np.float32) - np.float32(up.zero[up.L])) * np.float32(up.scale[up.L])
-            cur = CO.forward(on, cur, threads=thr, want_f=False)["q_out"]
-        dt = time.perf_counter() - t1
-        want = cur
-        diff = got.astype(np.int32) - want.astype(np.int32)
-        maxdiff = int(np.abs(diff).max())
-        parity = {"checked": f"full frame ({'x'.join(map(str, got.shape))}) of pool frame 0 vs C oracle", "max_abs_diff_int8": maxdiff,
-                  "mismatches": int((diff != 0).sum()),
-                  "psnr_db": "inf" if maxdiff == 0 else float(10 * np.log10(255.0 ** 2 / np.mean(diff.astype(np.float64) ** 2)))}
-        cpu = None
-        if world == 1 and not args.no_cpu_baseline:
-            cpu = {"value": round(1.0 / dt, 4), "unit": "frames/s", "cores": thr, "kind": "port",
-                   "sample": f"1 frame {H}x{W} of the same workload through oracle/sesrq_oracle.c (OpenMP, {thr} threads), {dt:.2f} s "
-                             "(the same run is the parity reference)"}
-
         # ---- end to end through pinned host buffers (never `value`): H2D / compute / D2H on three streams
         e2e = None
         if world == 1 and not args.no_e2e and B > 0:
@@ -223,7 +252,7 @@ def main():
                   "ms_per_step": round(elapsed_med / args.steps * 1e3, 5), "higher_is_better": True,
                   "scaling": "strong" if mode == "total" else "weak",
                   "vs_baseline": None, "dtype": "i8", "data": "synthetic",
-                  "repeats": args.repeats, "spread": {"min": round(fps_all[0], 2), "median": round(fps, 2), "max": round(fps_all[-1], 2)},
+                  "host_enqueue_us_per_step": None if res["host_enqueue_s_per_step"] is None else round(res["host_enqueue_s_per_step"] * 1e6, 1), "repeats": args.repeats, "blocks_fps": [round(args.steps * total_frames_per_step / e, 1) for e in res["elapsed"]], "spread": {"min": round(fps_all[0], 2), "median": round(fps, 2), "max": round(fps_all[-1], 2)},
                   "config": {"workload": desc, "name": args.workload, "frames_per_step_per_gpu": B, "frames_per_step": total_frames_per_step,
                              "streams": NS, "input_pool": f"{POOL} distinct resident frames, rotated per step",
                              "in": [B, cin, H, W], "out": list(shapes[-1]), "input_dtype": "f32", "output_dtype": "i8",

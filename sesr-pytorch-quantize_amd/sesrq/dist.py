@@ -32,7 +32,8 @@ def run_timed(group: "Group", step, steps: int, warmup: int, repeats: int = 1, s
     block's time is the MAX over ranks.  `units_per_step` = units (frames) THIS rank processes per step; the job's
     rate is the sum over ranks of units / the max-over-ranks time.  No data-path collective.
 
-    Returns {"elapsed": [s per block], "units_per_step_total": sum over ranks, "rates": [units/s per block]}."""
+    Returns {"elapsed": [s per block], "units_per_step_total": sum over ranks, "rates": [units/s per block],
+    "host_enqueue_s_per_step": host time per warm-up step}."""
     import time
     sync = sync or (lambda: None)
 
@@ -40,8 +41,10 @@ def run_timed(group: "Group", step, steps: int, warmup: int, repeats: int = 1, s
         sync()
         group.barrier()
 
+    tw = time.perf_counter()
     for _ in range(warmup):
         step()
+    host_s = (time.perf_counter() - tw) / warmup if warmup > 0 else None      # host time to ENQUEUE a step (the loop does not wait)
     elapsed = []
     for _ in range(max(1, repeats)):
         fence()
@@ -52,7 +55,7 @@ def run_timed(group: "Group", step, steps: int, warmup: int, repeats: int = 1, s
         elapsed.append(group.max_over_ranks(time.perf_counter() - t0))
     total_units = group.sum_over_ranks(units_per_step)
     return {"elapsed": elapsed, "units_per_step_total": total_units,
-            "rates": [steps * total_units / e for e in elapsed]}
+            "rates": [steps * total_units / e for e in elapsed], "host_enqueue_s_per_step": host_s}
 
 
 class Group:

@@ -130,11 +130,23 @@ class Engine:
         raise ValueError("input must be float32 (frame) or int8 (already quantised q0)")
 
     def forward(self, x: torch.Tensor, want_q: bool = True, want_f: bool = True, out_q=None, out_f=None, stream=None,
-                slot: int = 0):
+                slot: int = 0, assume_ordered: bool = False):
         """x: (N, Cin, H, W) float32 | int8 on self.device -> (q int8 | None, y float32 | None).
         stream: torch.cuda.Stream to enqueue on (default: current); slot: workspace copy to use -- give
-        concurrent in-flight frames different slots."""
+        concurrent in-flight frames different slots.  A side stream is ordered behind the current stream and the
+        tensors are recorded on it (safe default); assume_ordered=True skips that (and the device switch) for a caller
+        that owns persistent, contiguous buffers and fences its streams itself -- the throughput harness: the
+        bookkeeping costs more host time per call than the three kernel launches."""
         dt = self._check_in(x)
+        if assume_ordered:
+            if not x.is_contiguous() or (want_q and out_q is None) or (want_f and out_f is None) or stream is None:
+                raise ValueError("assume_ordered=True needs a contiguous input, caller-owned output buffers and a stream")
+            N, _, H, W = x.shape
+            ws = self.workspace(N, H, W, slot)
+            _lib.check(_lib.lib().sesrq_forward(self._h, x.data_ptr(), dt, out_q.data_ptr() if want_q else None,
+                                                out_f.data_ptr() if want_f else None, N, H, W, ws.data_ptr(), ws.numel(),
+                                                stream.cuda_stream))
+            return (out_q if want_q else None), (out_f if want_f else None)
         with torch.cuda.device(self.device):
             x = x.contiguous()
             N, _, H, W = x.shape
