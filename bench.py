@@ -83,6 +83,9 @@ def main():
     ap.add_argument("--no-fuse", action="store_true", help="one launch per layer (no fused hidden trio)")
     ap.add_argument("--wg-budget", type=int, default=0)
     ap.add_argument("--timing-iters", type=int, default=200, help="forwards of the per-launch HIP-event timing (roofline)")
+    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
+                    help="torch.distributed backend of the timing fence (nccl = RCCL; gloo + --share-gpu rehearses N > 1 on a 1-GPU box)")
+    ap.add_argument("--share-gpu", action="store_true", help="map every local rank onto the visible devices round-robin")
     ap.add_argument("--blocking-sync", action="store_true", help="fence with the blocking torch.cuda.synchronize() only")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-e2e", action="store_true")
@@ -106,9 +109,12 @@ def main():
     rank, local, world = env_world()
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device")
+    if args.share_gpu:
+        local = local % torch.cuda.device_count()
     torch.cuda.set_device(local)
     dev = torch.device(f"cuda:{local}")
-    grp = Group(backend="nccl", device=dev)      # RCCL; only the timing fence uses it
+    # RCCL ("nccl") on a multi-GPU node; only the timing fence uses it.  gloo reduces on the host.
+    grp = Group(backend=args.dist_backend, device=dev if args.dist_backend == "nccl" else None)
 
     fixtures, cin, H, W, (mode, nframes), desc = WORKLOADS[args.workload]
     bundles = [Bundle.load(os.path.join(ROOT, "tests", "golden", f)) for f in fixtures]
