@@ -7,6 +7,10 @@ models.*), re-drives the graph construction of the reference's calibration scrip
 scratch working directory, and harvests the ``output_pt/`` tree the reference writes into
 small ``.npz`` fixtures (plain arrays + a JSON string, loadable with allow_pickle=False).
 
+The fixtures define CPU-REFERENCE semantics: the reference as shipped runs on ``.cuda()``, where torch's tensor / Python-scalar
+division evaluates ``x * fl(1/s)`` and the input quantiser can differ by one LSB at rint ties from this CPU run (true fp32
+division).  No fixture covers a device run of the reference: parity against that variant is unpinned.
+
 Nothing of the reference travels: the fixtures hold inputs, parameters and expected
 outputs only.  The reference's two random input tensors (data files) are re-saved as
 ``.npy``.
