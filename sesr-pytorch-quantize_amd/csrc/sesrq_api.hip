@@ -115,17 +115,20 @@ static void pack_mfma_frags(const sesrq_layer_desc &d, int kind, bool general, b
                     else if (f == 5) { ky = g; kx = 4; }
                     else if (g == 0) { ky = 4; kx = 4; }
                 } else if (kind == MFMA_H5) {
-                    // per PE p two K-chunks: 0: lane group g = kernel row g, words = kx 0..3;  1: row 4 + column 4 by four
+                    // per PE p two K-chunks: 0: lane group g = one kernel row, words = kx 0..3;  1: row 4 + column 4 by four
                     // translates of the pixel pattern {(0,0),(1,0),(2,0),(2,2)} (same scheme as MFMA_F5)
+                    // lane groups of a 32-lane half are two image rows apart (bank-conflict-free LDS reads, sesrq_mfma.hip):
+                    // chunk 0: groups (0,1,2,3) = kernel rows (0,2,1,3); chunk 1: translations (0,4) (2,4) (2,0) (2,1)
                     const int fi = f >> 2, p = f & 3;
-                    static const int tr[4][2] = {{0, 4}, {2, 0}, {2, 1}, {2, 4}};
+                    static const int kyg[4] = {0, 2, 1, 3};
+                    static const int tr[4][2] = {{0, 4}, {2, 4}, {2, 0}, {2, 1}};
                     static const int pt[4][2] = {{0, 0}, {1, 0}, {2, 0}, {2, 2}};
                     ch = p + 4 * j;
-                    if (fi == 0) { ky = g; kx = i; }
+                    if (fi == 0) { ky = kyg[g]; kx = i; }
                     else {
                         ky = tr[g][0] + pt[i][0]; kx = tr[g][1] + pt[i][1];
                         const bool in_l = (ky == 4 && kx <= 4) || (kx == 4 && ky <= 4);
-                        if (!in_l || (g == 3 && i == 0)) ky = -1;
+                        if (!in_l || (g == 1 && i == 0)) ky = -1;          // tap (2,4) belongs to lane group 0
                     }
                 }
                 else if (kind == MFMA_H5P) {

@@ -355,7 +355,13 @@ __global__ __launch_bounds__(256) void mfma_h5_kernel(const ConvArgs a) {
     constexpr bool GENERAL = MODE == GEN_STD || MODE == GEN_ANY;
     constexpr int SW = MTW + 8;          // 2 + 64 + 2 halo, + over-read of the kx = 4..7 group
     constexpr int SH = MTH + 4;
-    constexpr int PW = GENERAL ? SW + 4 : 0;     // planar image: row pitch 4*76 = 304 dwords = 48 mod 64 banks
+    // planar image [row][PE][col]: plane pitch 78 dwords, row pitch 312 = 24 mod 32 banks.  With the lane groups of a 32-lane
+    // half (the conflict domain of ds_read_b32: lanes 0-31 = groups 0,1; 32-63 = groups 2,3) always TWO image rows apart --
+    // K-chunk 0: groups (0,1,2,3) = kernel rows (0,2,1,3); K-chunk 1: groups (0,1) = translations (0,4),(2,4), groups (2,3) =
+    // (2,0),(2,1) on the same row (overlapping lanes read the same address) -- the two 16-bank windows of a half are 16 banks
+    // apart: no bank conflict on either chunk (round 1: pitch 304, groups = rows 0..3: 2.2 M conflict cycles per launch of
+    // 11 M LDS cycles on the last layer, from the second chunk)
+    constexpr int PW = GENERAL ? SW + 6 : 0;
     constexpr int RP = 4 * PW;
     __shared__ int4 buf0[GENERAL ? SH * PW : SH * SW], buf1[GENERAL ? SH * PW : SH * SW];
     const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, n = l & 15, g = l >> 4;
@@ -374,7 +380,9 @@ __global__ __launch_bounds__(256) void mfma_h5_kernel(const ConvArgs a) {
     v4i A[NF];
 #pragma unroll
     for (int f = 0; f < NF; ++f) A[f] = ld_frag(fr + 4 + f * 64 + l);
-    const int tr1 = (g == 0 ? 0 : 2) * (GENERAL ? RP : SW) + (g == 0 ? 4 : (g == 1 ? 0 : (g == 2 ? 1 : 4)));    // chunk-1 translation (pixels; planar: dwords)
+    // per-PE chains (general, and the risky PE's chain of the hybrid mode); must match pack_mfma_frags (MFMA_H5 general)
+    const int kyg = ((g & 1) << 1) | (g >> 1);          // K-chunk 0: kernel row of lane group g = (0, 2, 1, 3)
+    const int tr1 = (g == 0 ? 0 : 2) * (GENERAL ? RP : SW) + (g < 2 ? 4 : g - 2);    // K-chunk 1 translation of group g: (0,4) (2,4) (2,0) (2,1) (pixels; planar: dwords)
     LastStore ls;
     if constexpr (EPI == EPI_LAST) ls.init(a, n_img, g, gx);
     v4i AR[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
@@ -410,7 +418,7 @@ __global__ __launch_bounds__(256) void mfma_h5_kernel(const ConvArgs a) {
                     acc[0] = mfma(A[5], C5, acc[0]);
                     acc[0] = mfma(A[6], C6, acc[0]);
                     if constexpr (MODE == HYB) {
-                        const int o0 = cb + (y + g) * SW * 4;          // K-chunk 0: row y+g, columns +0..3
+                        const int o0 = cb + (y + kyg) * SW * 4;        // K-chunk 0: row y+kyg, columns +0..3
                         const v4i b0 = {t32[o0], t32[o0 + 4], t32[o0 + 8], t32[o0 + 12]};
                         const int ob = cb + (y * SW + tr1) * 4;        // K-chunk 1: translated pixel pattern
                         const v4i b1 = {t32[ob], t32[ob + SW * 4], t32[ob + 2 * SW * 4], t32[ob + (2 * SW + 2) * 4]};
@@ -435,7 +443,7 @@ __global__ __launch_bounds__(256) void mfma_h5_kernel(const ConvArgs a) {
                     const v4i zero = {0, 0, 0, 0};
                     v4i acc[4];
                     const int *tw = reinterpret_cast<const int *>(tile);
-                    const int *c0 = tw + (y + g) * RP + col;            // chunk 0: row y+g, 4 adjacent pixels
+                    const int *c0 = tw + (y + kyg) * RP + col;          // chunk 0: row y+kyg, 4 adjacent pixels
                     const int *c1 = tw + y * RP + col + tr1;            // chunk 1: translated pattern (0,0) (1,0) (2,0) (2,2)
 #pragma unroll
                     for (int p = 0; p < 4; ++p) {
