@@ -46,15 +46,16 @@ WORKLOADS = {
 def launch_bytes_per_px(bundle, first, count, in_f32):
     """Algorithmic HBM bytes per input pixel of ONE launch covering layers first..first+count-1:
     every NHWC16 int8 activation that crosses a launch boundary is written once and read once, the residual operand
-    is re-read by the launch that holds layer L-2, the frame goes in as fp32 (or int8) and out as int8.  A fused
-    trio moves 16 in + 16 out (+16 residual) -- NOT the 112 B/px its three layers move one by one."""
+    is re-read by the launch that holds layer L-2 (unless layer 0 is in the same launch: the fused front keeps it in LDS),
+    the frame goes in as fp32 (or int8) and out as int8.  A fused trio moves 16 in + 16 out (+16 residual) -- NOT the
+    112 B/px its three layers move one by one; the fused front (layers 0-3) moves 4*Cin in + 16 out."""
     L = bundle.L
     cin = bundle.in_channels
     cout_last = int(bundle.layers[-1].wq.shape[0])
     last = first + count - 1
     rd = ((4 * cin) if in_f32 else cin) if first == 0 else 16
     wr = cout_last if last == L - 1 else 16
-    if first <= L - 2 <= last:
+    if first <= L - 2 <= last and first > 0:      # the fused front keeps the residual operand (its own layer-0 output) in LDS
         rd += 16
     return rd + wr
 
@@ -81,6 +82,7 @@ def main():
     ap.add_argument("--workload", default="sesr_x2_1080p", choices=sorted(WORKLOADS))
     ap.add_argument("--engine", default="auto", choices=["auto", "dot4", "mfma"])
     ap.add_argument("--no-fuse", action="store_true", help="one launch per layer (no fused hidden trio)")
+    ap.add_argument("--fuse", type=int, default=1, choices=[0, 1, 2], help="0 per layer, 1 (default) hidden trios, 2 + fused front")
     ap.add_argument("--wg-budget", type=int, default=0)
     ap.add_argument("--timing-iters", type=int, default=200, help="forwards of the per-launch HIP-event timing (roofline)")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
@@ -119,7 +121,7 @@ def main():
     fixtures, cin, H, W, (mode, nframes), desc = WORKLOADS[args.workload]
     bundles = [Bundle.load(os.path.join(ROOT, "tests", "golden", f)) for f in fixtures]
     ekw = dict(engine={"auto": _lib.ENGINE_AUTO, "dot4": _lib.ENGINE_DOT4, "mfma": _lib.ENGINE_MFMA}[args.engine],
-               fuse_hidden=not args.no_fuse, wg_budget=args.wg_budget)
+               fuse_hidden=0 if args.no_fuse else args.fuse, wg_budget=args.wg_budget)
     # chained nets: every net but the first takes the int8 output of the one before and re-quantises it into its own
     # input domain while staging (sesrq_options.i8_in_scale / i8_in_zero) -- no fp32 round trip through HBM
     engines = [sesrq.Engine(b, dev, upstream=(bundles[j - 1] if j else None), **ekw) for j, b in enumerate(bundles)]

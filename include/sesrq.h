@@ -43,8 +43,10 @@ typedef struct sesrq_options {
     int32_t anchor_add;      /* 1: add the nearest-upsampled fp32 input frame to the fp32 output (the x2 "anchor" of the
                               * reference's eval loop, test.py:148-155: gfake + inps_x2); needs Cin*r*r == Cout and an
                               * fp32 input; the int8 output is unaffected */
-    int32_t fuse_hidden;     /* 1 (default): run eligible runs of three hidden 3x3 layers as ONE launch (intermediates
-                              * stay in LDS); 0: one launch per layer */
+    int32_t fuse_hidden;     /* 1 (default): every eligible run of three hidden 3x3 layers is ONE launch (the residual-merging trio
+                              * first); 2: additionally run the first layer inside the same launch as that trio where the net allows
+                              * it (5-conv topologies, zero[1] == -128) -- bit-identical, one launch and 32 B/px of HBM traffic
+                              * fewer, measured ~2 % slower on two streams; 0: one launch per layer */
     int32_t wg_budget;       /* workgroup slots one launch may fill; 0 (default) = one full round of the chip (occupancy x CUs).
                               * The persistent kernels cut every 64-column strip into as many vertical runs as fit the budget:
                               * a small budget leaves compute units to a concurrent stream (and makes a workgroup walk many
@@ -138,7 +140,7 @@ int sesrq_forward_debug(const sesrq_net *net, const void *in, int in_dtype, void
                         const sesrq_taps *taps);
 
 /* The launch sequence of sesrq_forward for this net: launch j runs layers first[j] .. first[j]+count[j]-1
- * (count 3 = fused hidden trio).  Returns the number of launches (<= n_layers); first/count may be NULL. */
+ * (count 3 = fused hidden trio, 4 = first layer + trio).  Returns the number of launches (<= n_layers); first/count may be NULL. */
 int sesrq_launch_plan(const sesrq_net *net, int *first, int *count);
 
 /* Measurement hook: runs `iters` forwards back to back on `stream` with a HIP event pair around

@@ -253,7 +253,8 @@ int sesrq_create(const sesrq_net_desc *d, const sesrq_options *opts, sesrq_net *
     net->engine = o.engine;
     net->force_general = o.force_general ? 1 : 0;
     net->force_exact_div = o.exact_div ? 1 : 0;
-    net->fuse_hidden = o.fuse_hidden ? 1 : 0;
+    if (o.fuse_hidden < 0 || o.fuse_hidden > 2) { set_error("sesrq_create: fuse_hidden must be 0, 1 or 2"); delete net; return 1; }
+    net->fuse_hidden = o.fuse_hidden;
     if (o.wg_budget < 0) { set_error("sesrq_create: wg_budget must be >= 0"); delete net; return 1; }
     net->wg_budget = o.wg_budget;
     if (!(o.i8_in_scale >= 0.f) || o.i8_in_zero < -32768 || o.i8_in_zero > 127) { set_error("sesrq_create: bad int8 input domain"); delete net; return 1; }
@@ -350,6 +351,14 @@ int sesrq_create(const sesrq_net_desc *d, const sesrq_options *opts, sesrq_net *
         return k >= 1 && k <= L - 2 && lp.mfma_kind == MFMA_H3 && !lp.general && lp.ic == 16 && lp.oc == 16;
     };
     for (int k = L - 4; k >= 1 && trio_ok(k) && trio_ok(k + 1) && trio_ok(k + 2); k -= 3) net->trio_len[k] = 3;
+    // fused front (sesrq_quad.hip): the first layer feeds the residual-merging trio directly (the 5-conv reference topologies), its
+    // output IS the residual operand (zero[1] == -128), and its accumulation mode is merged or hybrid with the standard bit widths
+    {
+        const LayerPlan &l0 = net->layers[0];
+        const bool hyb0 = l0.general && __builtin_popcount(l0.risky_mask) == 1 && d->pe_acc_bits == 18 && d->pe_add_bits == 20 && l0.d_afrag_others;
+        net->quad_ok = L == 5 && net->trio_len[1] == 3 && !net->rc_separate && l0.mfma_kind == MFMA_F5 && l0.oc == 16 && d->layers[0].relu &&
+                       (!l0.general || hyb0);
+    }
     net->fd = prove_fastdiv(d->scale_in, d->zero[0]);
     net->layers[0].base.fd = net->fd;
     *out = net;
@@ -373,11 +382,16 @@ void sesrq_destroy(sesrq_net *net) {
 static bool trio_active(const sesrq_net *net, const sesrq_taps *taps) {
     return net->fuse_hidden && net->engine != SESRQ_ENGINE_DOT4 && !net->force_general && !taps;
 }
+// ... and so does the fused front (first layer + trio)
+static bool quad_active(const sesrq_net *net, const sesrq_taps *taps) {
+    return net->fuse_hidden >= 2 && net->quad_ok && trio_active(net, taps);
+}
 
 int sesrq_fast_division_proven(const sesrq_net *net) { return net ? net->fd.ok : 0; }
 
 const char *sesrq_layer_engine(const sesrq_net *net, int k) {
     if (!net || k < 0 || k >= net->L) return "";
+    if (quad_active(net, nullptr) && k < 4) return net->layers[0].general ? "mfma-quad-hybrid" : "mfma-quad-merged";
     for (int j = std::max(1, k - 2); j <= k; ++j)
         if (trio_active(net, nullptr) && net->trio_len[j] == 3 && k < j + 3) return "mfma-trio-merged";
     return net->layers[k].engine.c_str();
@@ -387,7 +401,7 @@ int sesrq_launch_plan(const sesrq_net *net, int *first, int *count) {
     if (!net) return 0;
     int n = 0;
     for (int k = 0; k < net->L;) {
-        const int c = (trio_active(net, nullptr) && net->trio_len[k] == 3) ? 3 : 1;
+        const int c = (k == 0 && quad_active(net, nullptr)) ? 4 : ((trio_active(net, nullptr) && net->trio_len[k] == 3) ? 3 : 1);
         if (first) first[n] = k;
         if (count) count[n] = c;
         ++n;
@@ -433,6 +447,44 @@ static int forward_impl(const sesrq_net *net, const void *in, int in_dtype, void
     int launch = 0;
     for (int k = 0; k < L; ++launch) {
         const LayerPlan &lp = net->layers[k];
+        if (k == 0 && quad_active(net, taps) && !(net->anchor_add && in_dtype != SESRQ_F32)) {
+            // ---- fused front: layers 0..3 in one launch (sesrq_quad.hip)
+            QuadArgs q;
+            memset(&q, 0, sizeof(q));
+            TrioArgs &t = q.t;
+            void *dst = bufA;
+            t.out = dst;
+            t.N = N; t.H = H; t.W = W;
+            t.wg_budget = net->wg_budget;
+            t.pad_in = net->layers[1].base.pad_word;
+            t.Mres = lp.base.Mres; t.shres = lp.base.shres; t.z_merge = lp.base.z_merge;
+            for (int j = 0; j < 3; ++j) {
+                const LayerPlan &lj = net->layers[1 + j];
+                t.l[j].afrag = lj.d_afrag_merged;
+                t.l[j].Mf = lj.base.Mf; t.l[j].sh = lj.base.sh; t.l[j].z_next = lj.base.z_next;
+                t.l[j].zlo = lj.base.relu ? fmaxf(lj.base.z_next, -128.f) : -128.f;
+                t.l[j].pad_next = net->layers[2 + j].base.pad_word;
+            }
+            q.frame = in;
+            q.afrag0 = lp.general ? lp.d_afrag_others : lp.d_afrag_merged;
+            q.afrag0r = lp.general ? lp.d_afrag_general : nullptr;
+            q.risky_pe = lp.general ? __builtin_ctz(lp.risky_mask) : 0;
+            q.ic = lp.ic;
+            q.Mf0 = lp.base.Mf; q.sh0 = lp.base.sh; q.z1 = lp.base.z_next;
+            q.zlo0 = fmaxf(lp.base.z_next, -128.f);
+            q.pad_raw = lp.base.pad_word;
+            q.s_in = lp.base.s_in; q.z_in = lp.base.z_in;
+            q.s_prev = net->i8_in_scale; q.z_prev = (float)net->i8_in_zero;
+            q.fd = net->fd;
+            if (net->force_exact_div) q.fd.ok = 0;
+            const int src = in_dtype == SESRQ_F32 ? SRC_F32 : (net->i8_in_scale > 0.f ? SRC_I8D : SRC_I8);
+            if (ev && hipEventRecord(ev[2 * launch], st) != hipSuccess) { set_error("hipEventRecord failed"); return 1; }
+            if (launch_quad(q, lp.general, src, st)) return 1;
+            if (ev && hipEventRecord(ev[2 * launch + 1], st) != hipSuccess) { set_error("hipEventRecord failed"); return 1; }
+            cur = dst;
+            k += 4;
+            continue;
+        }
         if (trio_active(net, taps) && net->trio_len[k] == 3) {
             // ---- fused hidden trio: layers k, k+1, k+2 in one launch (sesrq_trio.hip)
             TrioArgs t;

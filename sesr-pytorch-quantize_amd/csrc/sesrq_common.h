@@ -76,6 +76,19 @@ struct TrioArgs {
     TrioLayer l[3];
 };
 
+// fused front (sesrq_quad.hip): the first 5x5 layer + the hidden trio in one launch
+struct QuadArgs {
+    TrioArgs t;              // t.in / t.rc_in unused: the trio's input and the residual operand come from the first-layer phase
+    const void *frame;       // (N, ic, H, W) fp32 | int8
+    const int4 *afrag0;      // first layer: merged A-fragment image (hybrid: the image without the risky PE)
+    const int4 *afrag0r;     // hybrid: the general image (the risky PE's chain), else NULL
+    int risky_pe, ic;
+    float Mf0, sh0, z1, zlo0;
+    int pad_raw;             // zc of the frame's domain replicated into 4 bytes
+    float s_in, z_in, s_prev, z_prev;
+    FastDiv fd;
+};
+
 struct LayerPlan {
     int k, ic, oc, ocp;
     bool general;            // per-PE accumulators + 18/20-bit clamps needed
@@ -101,6 +114,7 @@ int launch_dot4(const LayerPlan &lp, const ConvArgs &a, int src, int epi, hipStr
 // mfma engine
 int launch_mfma(const LayerPlan &lp, const ConvArgs &a, int src, int epi, bool general, hipStream_t st, bool one_risky_pe = false);
 int launch_trio(const TrioArgs &a, int epi_c, hipStream_t st);
+int launch_quad(const QuadArgs &a, bool hybrid, int src, hipStream_t st);
 int launch_unpack_nhwc16(const void *nhwc, signed char *nchw, int N, int C, int H, int W, hipStream_t st);
 
 }  // namespace sesrq
@@ -122,6 +136,7 @@ struct sesrq_net {
     float i8_in_scale = 0.f;            // > 0: int8 input frames are in this (scale, zero) domain of an upstream net
     int i8_in_zero = 0;
     std::vector<int> trio_len;          // trio_len[k] == 3: layers k..k+2 are eligible for the fused hidden trio
+    bool quad_ok = false;               // layers 0..3 eligible for the fused front (first layer + residual-merging trio)
     int device = 0;
     bool rc_separate = false;   // zero[1] != -128 -> layer 0 writes its own rc tensor
     sesrq::FastDiv fd = {0, 0.f, 0.f, 0.f};

@@ -131,31 +131,6 @@ struct LastStore {
     }
 };
 
-// PE clamp / sum / adder clamp / add constant               (myQL/quan_func.py:370,380-386,437,491)
-template <int MODE>
-__device__ __forceinline__ void finish_sums(int s[4], const v4i *acc, const int4 ac, const ConvArgs &a) {
-    const int acv[4] = {ac.x, ac.y, ac.z, ac.w};
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        if constexpr (MODE == MERGED) {
-            s[i] = acc[0][i];       // add constant already in the accumulator (C-in)
-        } else if constexpr (MODE == HYB) {
-            // acc[0] = add constant + the three PEs that cannot saturate (load-time proof: each stays inside 18 bits, so their
-            // 18-bit clamps are no-ops), acc[1] = the risky PE.  |three safe sums + one clamped sum| <= 3*131072 + 131072
-            // = 2^19: the 20-bit adder clamp cannot fire either (quan_func.py:437 is a no-op here).
-            s[i] = acc[0][i] + clampi3(acc[1][i], -131072, 131071);
-        } else if constexpr (MODE == GEN_STD) {
-            const int t = clampi3(acc[0][i], -131072, 131071) + clampi3(acc[1][i], -131072, 131071) +
-                          clampi3(acc[2][i], -131072, 131071) + clampi3(acc[3][i], -131072, 131071);
-            s[i] = clampi3(t, -524288, 524287) + acv[i];
-        } else {
-            const int t = clampi3(acc[0][i], a.acc_lo, a.acc_hi) + clampi3(acc[1][i], a.acc_lo, a.acc_hi) +
-                          clampi3(acc[2][i], a.acc_lo, a.acc_hi) + clampi3(acc[3][i], a.acc_lo, a.acc_hi);
-            s[i] = clampi3(t, a.add_lo, a.add_hi) + acv[i];
-        }
-    }
-}
-
 // Staging of a (SH x SW) window of NHWC16 pixels, split in two phases so that a persistent
 // workgroup can keep the loads of its NEXT tile in flight while it computes the current one:
 //   load():  all buffer loads of a thread issued back to back (out-of-range -> 0)

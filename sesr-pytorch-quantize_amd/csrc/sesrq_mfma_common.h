@@ -141,6 +141,31 @@ __device__ __forceinline__ unsigned epi_preres(const int s[4], unsigned rcword, 
     return round_pack(w01, w23, -128.f, 127.f);
 }
 
+// PE clamp / sum / adder clamp / add constant               (myQL/quan_func.py:370,380-386,437,491)
+template <int MODE, class AT>
+__device__ __forceinline__ void finish_sums(int s[4], const v4i *acc, const int4 ac, const AT &a) {
+    const int acv[4] = {ac.x, ac.y, ac.z, ac.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        if constexpr (MODE == MERGED) {
+            s[i] = acc[0][i];       // add constant already in the accumulator (C-in)
+        } else if constexpr (MODE == HYB) {
+            // acc[0] = add constant + the three PEs that cannot saturate (load-time proof: each stays inside 18 bits, so their
+            // 18-bit clamps are no-ops), acc[1] = the risky PE.  |three safe sums + one clamped sum| <= 3*131072 + 131072
+            // = 2^19: the 20-bit adder clamp cannot fire either (quan_func.py:437 is a no-op here).
+            s[i] = acc[0][i] + clampi3(acc[1][i], -131072, 131071);
+        } else if constexpr (MODE == GEN_STD) {
+            const int t = clampi3(acc[0][i], -131072, 131071) + clampi3(acc[1][i], -131072, 131071) +
+                          clampi3(acc[2][i], -131072, 131071) + clampi3(acc[3][i], -131072, 131071);
+            s[i] = clampi3(t, -524288, 524287) + acv[i];
+        } else {
+            const int t = clampi3(acc[0][i], a.acc_lo, a.acc_hi) + clampi3(acc[1][i], a.acc_lo, a.acc_hi) +
+                          clampi3(acc[2][i], a.acc_lo, a.acc_hi) + clampi3(acc[3][i], a.acc_lo, a.acc_hi);
+            s[i] = clampi3(t, a.add_lo, a.add_hi) + acv[i];
+        }
+    }
+}
+
 // 4x4 transpose between lane groups (16 lanes each) and registers; its own inverse.
 // in : w[r] in lane (n, g) = word g of row r        out: w[g'] in lane (n, r') = word g' of row r'
 __device__ __forceinline__ void transpose4(unsigned w[4]) {
@@ -198,6 +223,15 @@ __device__ __forceinline__ void emit_rows4(const int s4[4][4], const AT &a, cons
         for (int r = 0; r < 4; ++r) rw[r] = epi_rc<BIASED>(s4[r], a);
         store_rows4(io.rc_out, io, y4, rw);
     }
+}
+
+// residual-merging rows with the residual operand words already in compute layout (lane (n, g): word g of pixel n of row r)
+template <bool BIASED, class AT>
+__device__ __forceinline__ void emit_rows4_preres_rc(const int s4[4][4], const unsigned rcw[4], const AT &a, const RowIO &io, int y4) {
+    unsigned w[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) w[r] = epi_preres<BIASED>(s4[r], rcw[r], a);
+    store_rows4(io.out, io, y4, w);
 }
 
 }  // namespace sesrq

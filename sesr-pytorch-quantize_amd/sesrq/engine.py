@@ -18,7 +18,7 @@ class Engine:
 
     def __init__(self, bundle: Bundle, device: Optional[torch.device] = None, engine: int = _lib.ENGINE_AUTO,
                  force_general: bool = False, exact_division: bool = False, anchor_add: bool = False,
-                 fuse_hidden: bool = True, wg_budget: int = 0, upstream: Optional[Bundle] = None):
+                 fuse_hidden=1, wg_budget: int = 0, upstream: Optional[Bundle] = None):
         """upstream: the net whose int8 OUTPUT frames this engine takes as int8 input (chained nets, e.g. nrdm_6 ->
         SESR-x2): they are re-quantised into this net's input domain while the first layer stages them."""
         if not torch.cuda.is_available():
@@ -49,7 +49,7 @@ class Engine:
         opts.force_general = int(bool(force_general))
         opts.exact_div = int(bool(exact_division))
         opts.anchor_add = int(bool(anchor_add))
-        opts.fuse_hidden = int(bool(fuse_hidden))
+        opts.fuse_hidden = 1 if fuse_hidden is True else int(fuse_hidden)     # 0 per layer, 1 (default) hidden trios, 2 + fused front
         opts.wg_budget = int(wg_budget)
         if upstream is not None:
             opts.i8_in_scale = float(np.float32(upstream.scale[upstream.L]))

@@ -19,6 +19,8 @@ def test_launch_bytes_match_the_survey_accounting():
     assert bench.layerwise_bytes_per_px(x2, True) == 168 and bench.layerwise_bytes_per_px(x2, False) == 159
     # as launched: first layer, fused trio (in + residual operand + out, NOT 32 + 32 + 48), last layer
     assert [bench.launch_bytes_per_px(x2, f, c, True) for f, c in ((0, 1), (1, 3), (4, 1))] == [28, 48, 28]
+    # fused front: fp32 frame in, one NHWC16 tensor out, the residual operand never leaves the CU
+    assert [bench.launch_bytes_per_px(x2, f, c, True) for f, c in ((0, 4), (4, 1))] == [28, 28]
     assert 168 * 1080 * 1920 == 348364800
     x4 = Bundle.load(os.path.join(GOLDEN, "sesr_x4.crop.npz"))
     assert bench.layerwise_bytes_per_px(x4, False) == 161          # SURVEY: SESR-x4 (1 -> 16): 161 B/px

@@ -18,10 +18,11 @@ from sesrq import _lib
 pytestmark = pytest.mark.gpu
 
 STAGE_FILES = [f for f in golden_files() if not f.endswith((".params.npz", "tables.npz", ".stimtxt.npz"))]
-# kernel families behind the same ABI: dot4 (one lane per pixel), mfma (one launch per layer), trio (the default: MFMA
-# kernels with every eligible run of three hidden 3x3 layers fused into one launch)
-ENGINES = [("dot4", dict(engine=_lib.ENGINE_DOT4)), ("mfma", dict(engine=_lib.ENGINE_MFMA, fuse_hidden=False)),
-           ("trio", dict(engine=_lib.ENGINE_MFMA, fuse_hidden=True))]
+# kernel families behind the same ABI: dot4 (one lane per pixel), mfma (one launch per layer), trio (MFMA kernels with every
+# eligible run of three hidden 3x3 layers fused into one launch: the default), quad (fuse_hidden=2: the first layer fused in
+# front of the residual-merging trio where the net allows it, trios elsewhere)
+ENGINES = [("dot4", dict(engine=_lib.ENGINE_DOT4)), ("mfma", dict(engine=_lib.ENGINE_MFMA, fuse_hidden=0)),
+           ("trio", dict(engine=_lib.ENGINE_MFMA, fuse_hidden=1)), ("quad", dict(engine=_lib.ENGINE_MFMA, fuse_hidden=2))]
 
 
 def make_engine(net, eng, **kw):
@@ -59,8 +60,15 @@ def test_golden_stage_by_stage(path, eng):
     res = e.forward_debug(xt, pe=use_pe)
     if eng[0] != "dot4":
         assert all(s.startswith("mfma") for s in e.layer_engines()), e.layer_engines()
-        assert ("mfma-trio-merged" in e.layer_engines()) == (eng[0] == "trio" and not any(
-            "general" in s or "hybrid" in s for s in e.layer_engines()[1:4])), e.layer_engines()
+        names = e.layer_engines()
+        hidden_merged = all(l.M > 0 for l in net.layers) and not any("general" in s_ or "hybrid" in s_ for s_ in
+                                                                     sesrq.Engine(bundle_from_oracle(net), _dev(), fuse_hidden=0).layer_engines()[1:4])
+        if eng[0] == "mfma":
+            assert not any("trio" in s_ or "quad" in s_ for s_ in names), names
+        elif eng[0] == "trio":
+            assert ("mfma-trio-merged" in names) == hidden_merged and not any("quad" in s_ for s_ in names), names
+        else:       # quad where the first layer is merged / hybrid and zero[1] == -128, else the trio
+            assert any("quad" in s_ or "trio" in s_ for s_ in names) == hidden_merged, names
     r = net.pixel_shuffle
     got = {k: v.cpu().numpy() for k, v in res.items()}
     # un-shuffle q_out to compare with input5
@@ -309,9 +317,9 @@ def test_config5_shape_nrdm6_then_sesr_x2_chain():
     _cmp("chain int8 output", q2, w2["q_out"])
     assert tuple(q2.shape) == (2, 3, 90, 166)
     # int8 hand-off: the second net takes the first one's int8 output and re-quantises it while staging
-    # (sesrq_options.i8_in_scale/zero) -- same bits as the fp32 hand-off, a quarter of the bytes, on both engines
+    # (sesrq_options.i8_in_scale/zero) -- same bits as the fp32 hand-off, a quarter of the bytes, on every first-layer kernel
     q1, _ = e1.forward(torch.from_numpy(x).to(_dev()), want_f=False)
-    for kw in (dict(), dict(engine=_lib.ENGINE_DOT4)):
+    for kw in (dict(), dict(fuse_hidden=2), dict(engine=_lib.ENGINE_DOT4)):
         e2i = sesrq.Engine(bundle_from_oracle(sr), _dev(), upstream=bundle_from_oracle(nr), **kw)
         q2i, _ = e2i.forward(q1)
         _cmp("chain int8 hand-off", q2i, w2["q_out"])
@@ -417,8 +425,10 @@ def test_trio_walk_shapes_and_chunking(budget):
     from oracle import c_oracle as CO
     for seed, kind in enumerate(["sesr_x2", "nrdm", "sesr_x4"]):
         net = O.synth_net(kind, 40 + seed)
+        eq = sesrq.Engine(bundle_from_oracle(net), _dev(), fuse_hidden=2, wg_budget=budget)
         et = sesrq.Engine(bundle_from_oracle(net), _dev(), wg_budget=budget)
-        el = sesrq.Engine(bundle_from_oracle(net), _dev(), fuse_hidden=False, wg_budget=budget)
+        el = sesrq.Engine(bundle_from_oracle(net), _dev(), fuse_hidden=0, wg_budget=budget)
+        assert eq.layer_engines()[:4] == ["mfma-quad-merged"] * 4 and eq.launch_plan() == [(0, 4), (4, 1)]
         assert et.layer_engines()[1:4] == ["mfma-trio-merged"] * 3 and et.launch_plan() == [(0, 1), (1, 3), (4, 1)]
         assert el.launch_plan() == [(k, 1) for k in range(5)]
         cin = net.layers[0].wq.shape[1]
@@ -427,10 +437,15 @@ def test_trio_walk_shapes_and_chunking(budget):
             xt = torch.from_numpy(x).to(_dev())
             q, y = et.forward(xt)
             q2, y2 = el.forward(xt)
+            q3, y3 = eq.forward(xt)
             want = CO.forward(net, x)
+            _cmp(f"{net.name} {N}x{H}x{W} budget {budget}: fused front vs oracle", q3, want["q_out"])
             _cmp(f"{net.name} {N}x{H}x{W} budget {budget}: trio vs oracle", q, want["q_out"])
             _cmp(f"{net.name} {N}x{H}x{W} budget {budget}: per-layer vs oracle", q2, want["q_out"])
-            _cmp("y", y, want["y"])
+            _cmp("y", y3, want["y"])
+            # the fused front also takes an already-quantised frame (and an upstream net's int8 output, test_config5_*)
+            q4, _ = eq.forward(torch.from_numpy(O.quantize_input(x, net.scale[0], net.zero[0])).to(_dev()))
+            _cmp(f"{net.name} {N}x{H}x{W} budget {budget}: fused front, int8 input", q4, want["q_out"])
 
 
 def test_trio_with_separate_residual_tensor_and_odd_zero_points():
@@ -439,7 +454,8 @@ def test_trio_with_separate_residual_tensor_and_odd_zero_points():
     net = O.synth_net("sesr_x2", 51)
     net.zero[1], net.zero[2], net.zero[3], net.zero[4] = -120, -101, -128, -77
     e = sesrq.Engine(bundle_from_oracle(net), _dev(), wg_budget=2)
-    assert "mfma-trio-merged" in e.layer_engines()
+    assert "mfma-trio-merged" in e.layer_engines() and e.launch_plan() == [(0, 1), (1, 3), (4, 1)]
+    assert sesrq.Engine(e.bundle, _dev(), fuse_hidden=2).launch_plan() == e.launch_plan()      # zero[1] != -128: no fused front
     for (N, H, W) in [(1, 19, 70), (2, 33, 121)]:
         x = rand_frame((N, 3, H, W), H)
         want = O.forward(net, x)
@@ -481,16 +497,19 @@ def test_config2_full_frame_1080p_on_the_timed_kernels():
     per-layer kernels must give the same bytes."""
     names = ["mfma-f5-hybrid", "mfma-trio-merged", "mfma-trio-merged", "mfma-trio-merged", "mfma-h5-general"]
     e, x, q = _full_frame_case("sesr_x2_rand.crop.npz", (1, 3, 1080, 1920), 1, names)
-    e2 = sesrq.Engine(e.bundle, _dev(), fuse_hidden=False)
+    e1 = sesrq.Engine(e.bundle, _dev(), fuse_hidden=2)
+    assert e1.layer_engines() == ["mfma-quad-hybrid"] * 4 + ["mfma-h5-general"]
+    e2 = sesrq.Engine(e.bundle, _dev(), fuse_hidden=0)
     assert e2.layer_engines() == ["mfma-f5-hybrid", "mfma-h3-merged", "mfma-h3-merged", "mfma-h3-merged", "mfma-h5-general"]
-    q2, _ = e2.forward(torch.from_numpy(x).to(_dev()))
-    assert torch.equal(q, q2)
+    for ee in (e1, e2):
+        q2, _ = ee.forward(torch.from_numpy(x).to(_dev()))
+        assert torch.equal(q, q2)
 
 
 def test_config3_full_frame_nrdm3_540p():
     """BASELINE config 3: nrdm_3 (reference checkpoint, reference calibration) 1x3x540x960, whole frame."""
-    _full_frame_case("nrdm_3.crop.npz", (1, 3, 540, 960), 3,
-                     ["mfma-f5-merged", "mfma-trio-merged", "mfma-trio-merged", "mfma-trio-merged", "mfma-h5p-merged"])
+    _full_frame_case("nrdm_3.crop.npz", (1, 3, 540, 960), 3, ["mfma-f5-merged"] + ["mfma-trio-merged"] * 3 + ["mfma-h5p-merged"])
+    _full_frame_case("nrdm_3.crop.npz", (1, 3, 540, 960), 3, ["mfma-quad-merged"] * 4 + ["mfma-h5p-merged"], fuse_hidden=2)
 
 
 def test_batch_larger_than_one_chip_round():
