@@ -8,7 +8,8 @@ reference's "push a delta image through the block":
     residual block:  W[c, c, mid, mid] += 1   (the short skip becomes part of the weights)
 
 (Float summation order differs from the reference's conv-based fold, so collapsed weights agree to
-rounding; parity of the integer path is pinned on the INT8 bundle, SURVEY 7 "hard parts".)"""
+rounding; parity of the integer path is pinned on the INT8 bundle, SURVEY 7 "hard parts".)  A block prepared for a QAT
+checkpoint (models/quantize_utils_pt.py) is not linear and is folded by its impulse response instead."""
 import torch
 from torch import nn
 
@@ -33,8 +34,22 @@ class CollapsibleLinearBlock(nn.Module):
         return self.activation(y)
 
     def _folded(self):
+        if type(self.conv_expand) is not nn.Conv2d:
+            return self._folded_by_probe()
         expand, squeeze = self.conv_expand.weight, self.conv_squeeze.weight[:, :, 0, 0]
         return torch.einsum("ot,tikl->oikl", squeeze, expand), self.conv_squeeze.bias
+
+    def _folded_by_probe(self):
+        """Fold of a block whose convs are not plain linear maps (models/quantize_utils_pt.py: fake-quantising convs of
+        a QAT checkpoint): the block's response to one unit impulse per input channel IS the reference's definition of
+        the collapsed kernel there (models/model_utils_pt.py:40-56 pushes a delta image through conv_squeeze(conv_expand(.))
+        and subtracts the bias), so the same ops run here, on the same tensor shapes, to get the same float32 bits."""
+        cin, k = self.conv_expand.in_channels, self.conv_expand.kernel_size[0]
+        probe = torch.zeros(cin, cin, k, k, device=self.conv_expand.weight.device)
+        probe[torch.arange(cin), torch.arange(cin), k // 2, k // 2] = 1.0
+        bias = self.conv_squeeze.bias
+        response = self.conv_squeeze(self.conv_expand(probe)) - bias[None, :, None, None]
+        return response.flip(2, 3).transpose(0, 1), bias
 
     def collapse(self):
         if self.collapsed:

@@ -25,6 +25,7 @@ from myQL.quan_func import (quantize_model_weight, quantize_asymmetrical_by_tens
 from myQL.quan_classes import NodeInsertMapping, FunctionPackage, NodeInsertMappingElement
 from myQL.graph_modify import insert_before, insert_bias_bypass, insert_after
 from models import sesr_sim, nrdm_3_sim, sesr_arch_sim, nrdm_6
+from models import quantize_utils_pt as quantize
 from sesrq.store import STORE
 
 # MFLAG -> net, as the reference's test_float.py:25-48 numbers them.  4 (nrdm_6, 8 convs) has no integer path in the
@@ -55,29 +56,27 @@ def float_model(mflag, ckpt=None, params=None):
     return model
 
 
-def load_checkpoint(model, ckpt, mflag):
-    """Load a reference float checkpoint into the plain collapsible net -- strictly.
+QAT_SKIP_ADDS = ("add_residual.", "add_upsampled_input.")
 
-    The reference only consumes a ``*_qat_G.pth`` after ``quantize.prepare()`` has wrapped every conv in a
-    QuantConv2d (reference sim.py:64-66, models/quantize_utils_pt.py:331,801): its ``collapse()`` then folds
-    through the weight / activation fake-quantisers, and the folded weights differ from a fold of the raw conv
-    weights (tens to hundreds of INT8 weights per net).  QAT modules are outside this package, so such a
-    checkpoint is REFUSED instead of being folded wrongly; the bundles the reference itself derives from them
-    are committed as tests/golden/{sesr_x4_qat,nrdm_3_qat}.params.npz (use --params).  Any other key mismatch
-    (a checkpoint of another net / --mflag) is refused as well: nothing may leave random-init weights behind."""
+
+def load_checkpoint(model, ckpt, mflag):
+    """Load a reference checkpoint into the collapsible net -- strictly.
+
+    A ``*_qat_G.pth`` (it carries ``*_quantizer.*`` entries) is only meaningful after ``quantize.prepare()`` has wrapped
+    every conv in a fake-quantising conv (reference sim.py:64-66): ``collapse()`` then folds THROUGH the quantisers, and
+    the folded weights differ from a fold of the raw conv weights by tens to hundreds of INT8 weights per net.  The
+    reference selects this with its ``qatf`` switch; here the checkpoint itself decides (models/quantize_utils_pt.py).
+    Entries of the two long-skip adds' quantisers (``add_residual.*``, ``add_upsampled_input.*``: QuantAdd state) are
+    dropped: the integer path merges the skip in the integer domain and never evaluates them.  Any other key mismatch (a checkpoint of another net / --mflag) is refused -- nothing may leave
+    random-init weights behind."""
     sd = torch.load(ckpt, weights_only=True, map_location="cpu")
     if isinstance(sd, dict) and "state_dict" in sd:
         sd = sd["state_dict"]
     if not isinstance(sd, dict):
         raise ValueError(f"{ckpt}: not a state_dict")
-    qat = [k for k in sd if "_quantizer." in k]
-    if qat:
-        raise ValueError(
-            f"{ckpt} is a QAT checkpoint ({len(qat)} *_quantizer.* entries, e.g. {qat[0]!r}): the reference folds it "
-            "through quantize.prepare()'s fake-quantisers (reference sim.py:64-66), which this package does not "
-            "implement -- folding the raw conv weights would give a different INT8 bundle.  Use the bundle the "
-            "reference derived from it: --params tests/golden/sesr_x4_qat.params.npz (sr_qat_G.pth) or "
-            "tests/golden/nrdm_3_qat.params.npz (nrdm_3_qat_G.pth).")
+    if quantize.is_qat_state_dict(sd):
+        quantize.prepare(model, inplace=True, a_bits=QUAN_BIT, w_bits=QUAN_BIT, q_type=0, q_level="C")
+        sd = {k: v for k, v in sd.items() if not k.startswith(QAT_SKIP_ADDS)}
     try:
         res = model.load_state_dict(sd, strict=False)
     except RuntimeError as e:           # tensor shape mismatch

@@ -166,21 +166,69 @@ def _plain_state_dict(mflag):
     return sim.MODELS[mflag]().state_dict()
 
 
-def test_qat_checkpoint_is_refused_loudly(tmp_path):
-    """A *_qat_G.pth carries weight_quantizer / activation_quantizer state that the reference consumes through
-    quantize.prepare() (reference sim.py:64-66); folding its raw conv weights would give another INT8 bundle
-    (45..1129 differing weights).  float_model must refuse it and point to the golden bundles."""
-    sd = _plain_state_dict(5)
-    sd["conv_first.conv_expand.weight_quantizer.scale"] = torch.ones(1)
-    sd["conv_first.conv_expand.activation_quantizer.observer.min_val"] = torch.zeros(1)
+def _qat_state_dict(mflag):
+    """A state_dict shaped like the reference's *_qat_G.pth: conv weights + the buffers of both quantisers of every conv
+    + the QuantAdd state of the long-skip adds."""
+    from models import quantize_utils_pt as quantize
+    torch.manual_seed(4)
+    m = quantize.prepare(sim.MODELS[mflag](), a_bits=8, w_bits=8, q_type=0, q_level="C")
+    sd = dict(m.state_dict())
+    for add in ("add_residual", "add_upsampled_input"):
+        sd[f"{add}.activation_quantizer.scale"] = torch.ones(1)
+        sd[f"{add}.observer_res.min_val"] = torch.zeros(1)
+    return sd
+
+
+def test_qat_checkpoint_is_folded_through_the_fake_quantisers(tmp_path):
+    """A *_qat_G.pth carries weight_quantizer / activation_quantizer state; the reference consumes it through
+    quantize.prepare() (reference sim.py:64-66) and its collapse() then folds THROUGH the fake-quantisers.  The loader
+    recognises such a checkpoint by its keys, prepares the net and folds it the same way: the result is NOT the fold of
+    the raw conv weights (45..1129 differing INT8 weights when folded silently)."""
+    from models import quantize_utils_pt as quantize
+    sd = _qat_state_dict(5)
+    assert sum("_quantizer." in k for k in sd) == 10 * 14 + 2 and "conv_first.conv_expand.weight_quantizer.observer.max_val" in sd
     p = tmp_path / "fake_qat_G.pth"
     torch.save(sd, p)
-    with pytest.raises(ValueError, match=r"QAT checkpoint.*--params"):
-        sim.float_model(5, ckpt=str(p))
+    m = sim.float_model(5, ckpt=str(p))
+    plain = tmp_path / "plain_G.pth"
+    torch.save({k: v for k, v in sd.items() if "quantizer" not in k and not k.startswith("add_")}, plain)
+    m0 = sim.float_model(5, ckpt=str(plain))
+    w, w0 = m.conv_first.conv_expand.weight, m0.conv_first.conv_expand.weight
+    assert type(m.conv_first.conv_expand) is torch.nn.Conv2d and w.shape == w0.shape == (16, 1, 5, 5)
+    d = (w - w0).abs().max().item()
+    assert 0 < d < 0.05 * w0.abs().max().item(), d                 # close to, but not, the linear fold
+    # the fold written out for the first block: impulse 1.0 -> 127/127.5 (128 clamps to 127), 8-bit weights, 8-bit hidden tensor
+    e, s_, bias = sd["conv_first.conv_expand.weight"], sd["conv_first.conv_squeeze.weight"], sd["conv_first.conv_squeeze.bias"]
+    fq = quantize.fake_quantize
+    hidden = fq(e, -127, 127)[:, 0] * np.float32(127 / 127.5)                     # (256, 5, 5): response to the unit impulse ...
+    hidden = torch.flip(hidden, [1, 2])                                           # ... laid out as the conv emits it
+    y = torch.einsum("ot,tkl->okl", fq(s_, -127, 127)[:, :, 0, 0], fq(hidden[None], -128, 127)[0])
+    np.testing.assert_allclose(torch.flip(y, [1, 2]).detach().numpy(), w[:, 0].detach().numpy(), rtol=0, atol=2e-6)
+    assert torch.equal(m.conv_first.conv_expand.bias, bias)
     # the calibration entry goes through the same loader
     import test as calib_entry
-    with pytest.raises(ValueError, match="QAT checkpoint"):
-        calib_entry.sim.float_model(5, ckpt=str(p))
+    assert torch.equal(calib_entry.sim.float_model(5, ckpt=str(p)).conv_first.conv_expand.weight, w)
+    # a QAT checkpoint of another net is still refused
+    with pytest.raises(ValueError, match="does not fit the MFLAG 3 net"):
+        sim.float_model(3, ckpt=str(p))
+
+
+def test_fake_quantize_known_answers_and_prepare_options():
+    from models import quantize_utils_pt as quantize
+    t = torch.tensor([0.0, 1.0, -0.5, 0.0019607844, 0.0058823530])       # span 1 -> s = 1/127.5; 0.25 -> 0, 0.75 -> 1
+    got = quantize.fake_quantize(t, -128, 127)
+    s = np.float32(1.0) / np.float32(127.5)
+    np.testing.assert_array_equal(got.numpy(), np.array([0, 127, -64, 0, 1], np.float32) * s)   # 127.5 -> 128 -> clamp 127; 63.75 -> 64
+    np.testing.assert_array_equal(quantize.fake_quantize(torch.tensor([3.0, -1.0, 5.0, 254.0]), -127, 127).numpy(),
+                                  np.array([4, -2, 6, 254], np.float32))             # s = 2: 1.5, -0.5, 2.5 round AWAY from zero
+    assert quantize.fake_quantize(torch.zeros(3), -127, 127).abs().max() == 0                     # eps floor on the scale, no 0/0
+    net = sim.MODELS[3]()
+    for bad in (dict(q_type=1, q_level="C"), dict(q_level=0), dict(q_level="C", a_bits=32), dict(q_level="C", qaft=True)):
+        with pytest.raises(ValueError, match=r"prepare\(\)"):
+            quantize.prepare(net, **bad)
+    m = quantize.prepare(net, q_level="C")
+    assert m is not net and type(net.conv_first.conv_expand) is torch.nn.Conv2d                   # inplace=False copies
+    assert type(m.conv_first.conv_squeeze) is quantize.QuantConv2d and quantize.prepare(m, inplace=True, q_level="C") is m
 
 
 def test_checkpoint_of_another_net_is_refused(tmp_path):
@@ -199,11 +247,31 @@ REF_PARAMS = "/root/reference/model_params"
 
 
 @pytest.mark.skipif(not os.path.isdir(REF_PARAMS), reason="reference checkpoints not present (build container only)")
-@pytest.mark.parametrize("name", ["sr_qat_G.pth", "nrdm_3_qat_G.pth", "nrdm_6_qat_G.pth"])
-def test_reference_qat_checkpoints_are_refused(name):
-    mflag = {"sr_qat_G.pth": 5, "nrdm_3_qat_G.pth": 3, "nrdm_6_qat_G.pth": 4}[name]
-    with pytest.raises(ValueError, match="QAT checkpoint"):
-        sim.float_model(mflag, ckpt=os.path.join(REF_PARAMS, name))
+@pytest.mark.parametrize("ckpt,mflag,case", [("sr_qat_G.pth", 5, "sesr_x4_qat"), ("nrdm_3_qat_G.pth", 3, "nrdm_3_qat")])
+def test_reference_qat_checkpoint_folds_to_the_golden_weights(ckpt, mflag, case):
+    """BASELINE config 1's checkpoint (sr_qat_G.pth) and nrdm_3_qat_G.pth, --ckpt path end to end on the host: QAT fold ->
+    the collapsed float32 weights the reference itself derived (tests/golden/*_qat.params.npz, written by running the
+    reference: same torch ops on the same shapes, so equal to the BIT) -> weight quantiser -> the reference's Wq."""
+    STORE.clear()
+    fx, meta = load_fixture(os.path.join(GOLDEN, f"{case}.crop.npz"))
+    STORE.set_activation_domains(meta["scale"], meta["zero"])
+    fm = sim.float_model(mflag, ckpt=os.path.join(REF_PARAMS, ckpt))
+    z = np.load(os.path.join(GOLDEN, f"{case}.params.npz"))
+    convs = [fm.conv_first.conv_expand] + [b.conv_expand for b in fm.residual_block] + [fm.conv_last.conv_expand]
+    for k, c in enumerate(convs):
+        np.testing.assert_array_equal(c.weight.detach().numpy(), z[f"Wf{k}"])
+        np.testing.assert_array_equal(c.bias.detach().numpy(), z[f"bf{k}"])
+    b = sim.splice(fm).sesrq_bundle()
+    for k in range(5):
+        np.testing.assert_array_equal(b.layers[k].wq, fx[f"Wq{k}"])
+
+
+@pytest.mark.skipif(not os.path.isdir(REF_PARAMS), reason="reference checkpoints not present (build container only)")
+def test_reference_nrdm6_qat_checkpoint_loads_and_folds():
+    """nrdm_6_qat_G.pth (8 convs): loads key for key and folds; no golden (the reference has no integer path at this depth)."""
+    fm = sim.float_model(4, ckpt=os.path.join(REF_PARAMS, "nrdm_6_qat_G.pth"))
+    assert len(fm.residual_block) == 6 and all(type(b.conv_expand) is torch.nn.Conv2d for b in fm.residual_block)
+    assert all(torch.isfinite(b.conv_expand.weight).all() for b in fm.residual_block)
 
 
 @pytest.mark.skipif(not os.path.isdir(REF_PARAMS), reason="reference checkpoints not present (build container only)")
