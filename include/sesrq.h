@@ -39,7 +39,13 @@ enum { SESRQ_ENGINE_AUTO = 0, SESRQ_ENGINE_DOT4 = 1, SESRQ_ENGINE_MFMA = 2 };
 typedef struct sesrq_options {
     int32_t engine;          /* SESRQ_ENGINE_*                                                        (default AUTO) */
     int32_t force_general;   /* 1: always run the per-PE clamp path, even where a load-time proof says it is a no-op */
-    int32_t exact_div;       /* 1: IEEE division in the input quantiser even if the fast form is proven         */
+    int32_t exact_div;       /* how the input quantiser forms x / s0 (myQL/quan_func.py:225).  0 (default): the true fp32 quotient --
+                              * what torch evaluates on a CPU and what every golden vector pins -- by a 3-instruction form
+                              * where sesrq_create proved it bit-identical, else by the division instruction (the first layer
+                              * then runs on the dot4 kernel: the MFMA first-layer kernels only carry the 3-instruction form);
+                              * 1: always the division instruction; 2: x * fl(1/s0), what torch evaluates for tensor / scalar on a GPU (the
+                              * reference's scripts call .cuda()): differs from the quotient by an ulp at most, i.e. q0 by one
+                              * LSB at rounding ties only -- parity UNPINNED (no fixture of a GPU-run reference exists) */
     int32_t anchor_add;      /* 1: add the nearest-upsampled fp32 input frame to the fp32 output (the x2 "anchor" of the
                               * reference's eval loop, test.py:148-155: gfake + inps_x2); needs Cin*r*r == Cout and an
                               * fp32 input; the int8 output is unaffected */

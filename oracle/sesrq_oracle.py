@@ -150,9 +150,13 @@ def _sat(x, bits):
     return np.clip(x, -(2 ** (bits - 1)), 2 ** (bits - 1) - 1)
 
 
-def quantize_input(x: np.ndarray, s0: float, z0: int) -> np.ndarray:
-    """q0 = clamp8(rint(x / f32(s0) + f32(z0)))   -- myQL/quan_func.py:222-225 (true fp32 division)."""
-    return np.clip(np.rint(np.asarray(x, F32) / F32(s0) + F32(z0)), -128, 127).astype(np.int8)
+def quantize_input(x: np.ndarray, s0: float, z0: int, reciprocal: bool = False) -> np.ndarray:
+    """q0 = clamp8(rint(x / f32(s0) + f32(z0)))   -- myQL/quan_func.py:222-225 (true fp32 division).
+    reciprocal=True: x * f32(1 / f32(s0)) instead of the quotient -- how torch evaluates tensor / scalar on a GPU, where
+    the reference's scripts run; no fixture pins it (the goldens come from a CPU run)."""
+    x = np.asarray(x, F32)
+    t = x * (F32(1) / F32(s0)) if reciprocal else x / F32(s0)
+    return np.clip(np.rint(t + F32(z0)), -128, 127).astype(np.int8)
 
 
 def conv_pe(q: np.ndarray, lay: Layer, z_in: int, pe: int, acc_bits: int, add_bits: int, return_raw: bool = False):

@@ -252,7 +252,8 @@ int sesrq_create(const sesrq_net_desc *d, const sesrq_options *opts, sesrq_net *
     net->rc_separate = (d->zero[1] != -128);
     net->engine = o.engine;
     net->force_general = o.force_general ? 1 : 0;
-    net->force_exact_div = o.exact_div ? 1 : 0;
+    if (o.exact_div < 0 || o.exact_div > 2) { set_error("sesrq_create: exact_div must be 0, 1 or 2"); delete net; return 1; }
+    net->div_mode = o.exact_div;
     if (o.fuse_hidden < 0 || o.fuse_hidden > 2) { set_error("sesrq_create: fuse_hidden must be 0, 1 or 2"); delete net; return 1; }
     net->fuse_hidden = o.fuse_hidden;
     if (o.wg_budget < 0) { set_error("sesrq_create: wg_budget must be >= 0"); delete net; return 1; }
@@ -359,8 +360,18 @@ int sesrq_create(const sesrq_net_desc *d, const sesrq_options *opts, sesrq_net *
         net->quad_ok = L == 5 && net->trio_len[1] == 3 && !net->rc_separate && l0.mfma_kind == MFMA_F5 && l0.oc == 16 && d->layers[0].relu &&
                        (!l0.general || hyb0);
     }
-    net->fd = prove_fastdiv(d->scale_in, d->zero[0]);
+    net->fd_proof = prove_fastdiv(d->scale_in, d->zero[0]);
+    net->fd = net->fd_proof;
+    if (net->div_mode == 1) net->fd.ok = 0;
+    if (net->div_mode == 2) {
+        net->fd = reciprocal_form(d->scale_in, d->zero[0]);
+        if (!net->fd.ok) { set_error("sesrq_create: exact_div = 2 needs a finite positive scale_in"); delete net; return 1; }
+    }
     net->layers[0].base.fd = net->fd;
+    if (!net->fd.ok) {      // no 3-instruction form for this (scale, zero), or exact_div = 1: layer 0 divides, on the dot4 kernel
+        net->layers[0].engine = net->layers[0].engine_dot4;
+        net->quad_ok = false;
+    }
     *out = net;
     return 0;
 }
@@ -387,7 +398,7 @@ static bool quad_active(const sesrq_net *net, const sesrq_taps *taps) {
     return net->fuse_hidden >= 2 && net->quad_ok && trio_active(net, taps);
 }
 
-int sesrq_fast_division_proven(const sesrq_net *net) { return net ? net->fd.ok : 0; }
+int sesrq_fast_division_proven(const sesrq_net *net) { return net ? net->fd_proof.ok : 0; }
 
 const char *sesrq_layer_engine(const sesrq_net *net, int k) {
     if (!net || k < 0 || k >= net->L) return "";
@@ -476,7 +487,6 @@ static int forward_impl(const sesrq_net *net, const void *in, int in_dtype, void
             q.s_in = lp.base.s_in; q.z_in = lp.base.z_in;
             q.s_prev = net->i8_in_scale; q.z_prev = (float)net->i8_in_zero;
             q.fd = net->fd;
-            if (net->force_exact_div) q.fd.ok = 0;
             const int src = in_dtype == SESRQ_F32 ? SRC_F32 : (net->i8_in_scale > 0.f ? SRC_I8D : SRC_I8);
             if (ev && hipEventRecord(ev[2 * launch], st) != hipSuccess) { set_error("hipEventRecord failed"); return 1; }
             if (launch_quad(q, lp.general, src, st)) return 1;
@@ -516,7 +526,6 @@ static int forward_impl(const sesrq_net *net, const void *in, int in_dtype, void
         a.wpk = eff.general ? lp.d_wpk_general : lp.d_wpk_merged;
         a.N = N; a.H = H; a.W = W;
         a.wg_budget = net->wg_budget;
-        if (net->force_exact_div) a.fd.ok = 0;
         a.in = cur;
         int src = (k == 0) ? (in_dtype == SESRQ_F32 ? SRC_F32 : (net->i8_in_scale > 0.f ? SRC_I8D : SRC_I8)) : SRC_NHWC16;
         a.s_prev = net->i8_in_scale; a.z_prev = (float)net->i8_in_zero;
@@ -540,7 +549,7 @@ static int forward_impl(const sesrq_net *net, const void *in, int in_dtype, void
             }
         }
         if (ev && hipEventRecord(ev[2 * launch], st) != hipSuccess) { set_error("hipEventRecord failed"); return 1; }
-        const bool use_mfma = net->engine != SESRQ_ENGINE_DOT4 && lp.mfma_kind != MFMA_NONE && !dbg && !q0tap;
+        const bool use_mfma = net->engine != SESRQ_ENGINE_DOT4 && lp.mfma_kind != MFMA_NONE && !dbg && !q0tap && (k > 0 || net->fd.ok);
         if (use_mfma) {
             a.afrag = eff.general ? lp.d_afrag_general : lp.d_afrag_merged;
             // exactly one PE can saturate (and nothing forces the full per-PE path): merged chain + that PE's chain

@@ -15,11 +15,16 @@ enum MfmaKind { MFMA_NONE = 0, MFMA_H3 = 1, MFMA_H5 = 2, MFMA_F5 = 3, MFMA_H5P =
 
 // Verified fast division of the input quantiser (sesrq_verify.hip): q0(x) with x pre-clamped to
 // [xlo, xhi] and x/s formed as fma(fma(-s, x*r, x), r, x*r); ok == 1 only after an exhaustive proof.
+// ok == 0: the division instruction.  ok == 1: q = xc * r, x/s := fma(fma(-s, q, xc), r2, q) with xc = x clamped to [xlo, xhi]:
+//   r2 == r is the form prove_fastdiv proves bit-identical to the division; r2 == 0 with r = fl(1/s) and an unbounded clamp is
+//   the plain reciprocal multiply x * fl(1/s) of option exact_div = 2 (fd_reciprocal()).
 struct FastDiv {
     int ok;
-    float r, xlo, xhi;
+    float r, r2, xlo, xhi;
 };
+__host__ __device__ inline bool fd_reciprocal(const FastDiv &fd) { return fd.ok && fd.r2 == 0.f; }
 FastDiv prove_fastdiv(float s, int zero);
+FastDiv reciprocal_form(float s, int zero);
 
 // Per-launch arguments of one conv layer.  Lives in the kernarg segment (SGPR loads).
 struct ConvArgs {
@@ -50,7 +55,7 @@ struct ConvArgs {
     float z_merge;           // EPI_PRERES: zero of the last conv's input domain
     float s_in, z_in;        // SRC_F32: f32(scale_0), (float)zero_0
     float s_prev, z_prev;    // SRC_I8D: the upstream net's f32(scale_L), (float)zero_L: x = (q - z_prev) * s_prev, then the input quantiser
-    FastDiv fd;              // SRC_F32: proven fast form of x / s_in (fd.ok == 0 -> IEEE division)
+    FastDiv fd;              // SRC_F32 / SRC_I8D: how x / s_in is formed (FD_*)
     float s_out, z_out;      // EPI_LAST: f32(scale_L), (float) zero_L
     int relu;
     int ps;                  // EPI_LAST pixel shuffle factor
@@ -129,7 +134,8 @@ struct sesrq_net {
     int acc_bits = 18, add_bits = 20;
     int engine = SESRQ_ENGINE_AUTO;     // options are fixed at sesrq_create: the net is immutable afterwards
     int force_general = 0;
-    int force_exact_div = 0;
+    int div_mode = 0;        // sesrq_options.exact_div
+    sesrq::FastDiv fd_proof = {0, 0.f, 0.f, 0.f, 0.f};        // what prove_fastdiv found, whatever form the options select
     int anchor_add = 0;
     int fuse_hidden = 1;
     int wg_budget = 0;
@@ -139,5 +145,5 @@ struct sesrq_net {
     bool quad_ok = false;               // layers 0..3 eligible for the fused front (first layer + residual-merging trio)
     int device = 0;
     bool rc_separate = false;   // zero[1] != -128 -> layer 0 writes its own rc tensor
-    sesrq::FastDiv fd = {0, 0.f, 0.f, 0.f};
+    sesrq::FastDiv fd = {0, 0.f, 0.f, 0.f, 0.f};
 };

@@ -64,10 +64,10 @@ __global__ __launch_bounds__(256) void conv_dot4_kernel(const ConvArgs a) {
                     int q;
                     if constexpr (SRC == SRC_F32) {
                         const float xv = reinterpret_cast<const float *>(a.in)[off];
-                        q = (int)q8f(__fadd_rn(__fdiv_rn(xv, a.s_in), a.z_in));
+                        q = (int)q8f(__fadd_rn((fd_reciprocal(a.fd) ? __fmul_rn(xv, a.fd.r) : __fdiv_rn(xv, a.s_in)), a.z_in));
                     } else if constexpr (SRC == SRC_I8D) {
                         const float xv = __fmul_rn((float)(int)reinterpret_cast<const signed char *>(a.in)[off] - a.z_prev, a.s_prev);
-                        q = (int)q8f(__fadd_rn(__fdiv_rn(xv, a.s_in), a.z_in));
+                        q = (int)q8f(__fadd_rn((fd_reciprocal(a.fd) ? __fmul_rn(xv, a.fd.r) : __fdiv_rn(xv, a.s_in)), a.z_in));
                     } else {
                         q = reinterpret_cast<const signed char *>(a.in)[off];
                     }

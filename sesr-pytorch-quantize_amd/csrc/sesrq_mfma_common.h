@@ -20,30 +20,21 @@ __device__ __forceinline__ int clampi3(int v, int lo, int hi) { return min(max(v
 __device__ __forceinline__ v4i ld_frag(const int4 *p) { const int4 t = *p; v4i r = {t.x, t.y, t.z, t.w}; return r; }
 __device__ __forceinline__ unsigned fbits(float f) { return __builtin_bit_cast(unsigned, f); }
 
-// input quantiser q0 = clamp8(rint(fl(fl(x/s) + z)))  (myQL/quan_func.py:225), as a float in [-128,127]
-__device__ __forceinline__ float quantize_in(float x, float s, float z, const FastDiv &fd) {
-    float t;
-    if (fd.ok) {                       // proven bit-identical for this (s, z): sesrq_verify.hip
-        const float xc = med3(x, fd.xlo, fd.xhi);
-        const float q = __fmul_rn(xc, fd.r);
-        t = __builtin_fmaf(__builtin_fmaf(-s, q, xc), fd.r, q);
-    } else {
-        t = __fdiv_rn(x, s);
-    }
-    return med3(rintf(__fadd_rn(t, z)), -128.f, 127.f);
+// x / s of the input quantiser, three instructions, NO test of fd.ok: the MFMA first-layer kernels run only when sesrq_create
+// selected this form (fd.ok == 1; otherwise sesrq_api.hip sends layer 0 to the dot4 kernel, which divides) -- a wave-uniform
+// test per value cut the staging code into 280 small blocks and cost the first layer 5 % (24.8 -> 23.5 us at 1080p).
+// The reciprocal form (option exact_div = 2) rides on the same instructions with r2 = 0: fma(e, 0, q) == q for the finite e
+// the clamped x gives.
+__device__ __forceinline__ float quotient_in(float x, float s, const FastDiv &fd) {
+    const float xc = med3(x, fd.xlo, fd.xhi);
+    const float q = __fmul_rn(xc, fd.r);
+    return __builtin_fmaf(__builtin_fmaf(-s, q, xc), fd.r2, q);
 }
-// same value as the low byte (two's complement) of the returned word: clamp the un-rounded value, then round to nearest
-// even by adding 1.5 * 2^23 (clamp and rint commute for integer bounds) -- no v_rndne / v_cvt_i32
+// input quantiser q0 = clamp8(rint(fl(fl(x/s) + z)))  (myQL/quan_func.py:225) as the low byte (two's complement) of the
+// returned word: clamp the un-rounded value, then round to nearest even by adding 1.5 * 2^23 (clamp and rint commute for
+// integer bounds) -- no v_rndne / v_cvt_i32
 __device__ __forceinline__ unsigned quantize_in_bits(float x, float s, float z, const FastDiv &fd) {
-    float t;
-    if (fd.ok) {
-        const float xc = med3(x, fd.xlo, fd.xhi);
-        const float q = __fmul_rn(xc, fd.r);
-        t = __builtin_fmaf(__builtin_fmaf(-s, q, xc), fd.r, q);
-    } else {
-        t = __fdiv_rn(x, s);
-    }
-    return __builtin_bit_cast(unsigned, __fadd_rn(med3(__fadd_rn(t, z), -128.f, 127.f), 12582912.f));
+    return __builtin_bit_cast(unsigned, __fadd_rn(med3(__fadd_rn(quotient_in(x, s, fd), z), -128.f, 127.f), 12582912.f));
 }
 
 // general path: the MFMA operand of PE P = word P of four staged pixels.  Two v_pk_mov_b32 build the

@@ -45,9 +45,26 @@ __global__ void verify_fastdiv_kernel(unsigned b0, unsigned b1, float s, float r
 static std::mutex g_mu;
 static std::map<std::pair<unsigned, int>, FastDiv> g_cache;
 
+// Option exact_div = 2: x * fl(1/s) on the proven form's instructions (r2 = 0).  x is clamped to the same saturating range
+// first -- multiplication by r > 0 is monotonic and both bounds quantise 8 steps beyond the int8 range, so the clamp changes no
+// result, and it keeps x * r finite (fma(-inf, 0, inf) would be NaN).  ok == 0 (division) if the range is degenerate.
+FastDiv reciprocal_form(float s, int zero) {
+    FastDiv fd;
+    fd.ok = 0; fd.r = 0.f; fd.r2 = 0.f; fd.xlo = 0.f; fd.xhi = 0.f;
+    if (!(s > 0.f) || !std::isfinite(s)) return fd;
+    fd.r = 1.0f / s;
+    fd.xlo = (float)((-136.0 - (double)zero) * (double)s);
+    fd.xhi = (float)((135.0 - (double)zero) * (double)s);
+    const float z = (float)zero;
+    const bool ok = std::isfinite(fd.r) && fd.r > 0.f && std::isfinite(fd.xlo) && std::isfinite(fd.xhi) &&
+                    rintf(fd.xlo * fd.r + z) <= -129.f && rintf(fd.xhi * fd.r + z) >= 128.f;
+    fd.ok = ok ? 1 : 0;
+    return fd;
+}
+
 FastDiv prove_fastdiv(float s, int zero) {
     FastDiv fd;
-    fd.ok = 0; fd.r = 0.f; fd.xlo = 0.f; fd.xhi = 0.f;
+    fd.ok = 0; fd.r = 0.f; fd.r2 = 0.f; fd.xlo = 0.f; fd.xhi = 0.f;
     if (!(s > 0.f) || !std::isfinite(s)) return fd;
     const std::pair<unsigned, int> key(__builtin_bit_cast(unsigned, s), zero);
     {
@@ -56,7 +73,7 @@ FastDiv prove_fastdiv(float s, int zero) {
         if (it != g_cache.end()) return it->second;
     }
     const float z = (float)zero;
-    fd.r = (float)(1.0L / (long double)s);
+    fd.r = fd.r2 = (float)(1.0L / (long double)s);
     fd.xlo = (float)((-136.0 - (double)zero) * (double)s);
     fd.xhi = (float)((135.0 - (double)zero) * (double)s);
     bool ok = std::isfinite(fd.r) && std::isfinite(fd.xlo) && std::isfinite(fd.xhi) && fd.r > 0.f;

@@ -18,8 +18,10 @@ class Engine:
 
     def __init__(self, bundle: Bundle, device: Optional[torch.device] = None, engine: int = _lib.ENGINE_AUTO,
                  force_general: bool = False, exact_division: bool = False, anchor_add: bool = False,
-                 fuse_hidden=1, wg_budget: int = 0, upstream: Optional[Bundle] = None):
-        """upstream: the net whose int8 OUTPUT frames this engine takes as int8 input (chained nets, e.g. nrdm_6 ->
+                 fuse_hidden=1, wg_budget: int = 0, upstream: Optional[Bundle] = None, reciprocal_division: bool = False):
+        """reciprocal_division: form x / s0 of the input quantiser as x * fl(1/s0) -- torch's tensor / scalar on a GPU --
+        instead of the true quotient the CPU-run reference and the goldens define (sesrq_options.exact_div = 2).
+        upstream: the net whose int8 OUTPUT frames this engine takes as int8 input (chained nets, e.g. nrdm_6 ->
         SESR-x2): they are re-quantised into this net's input domain while the first layer stages them."""
         if not torch.cuda.is_available():
             raise RuntimeError("sesrq.Engine needs a HIP device (torch.cuda.is_available() is False); "
@@ -47,7 +49,9 @@ class Engine:
         _lib.lib().sesrq_default_options(C.byref(opts))
         opts.engine = int(engine)
         opts.force_general = int(bool(force_general))
-        opts.exact_div = int(bool(exact_division))
+        if exact_division and reciprocal_division:
+            raise ValueError("exact_division and reciprocal_division exclude each other")
+        opts.exact_div = 2 if reciprocal_division else int(bool(exact_division))
         opts.anchor_add = int(bool(anchor_add))
         opts.fuse_hidden = 1 if fuse_hidden is True else int(fuse_hidden)     # 0 per layer, 1 (default) hidden trios, 2 + fused front
         opts.wg_budget = int(wg_budget)

@@ -204,7 +204,10 @@ def test_fast_division_is_proven_and_equals_exact_division():
     b = bundle_from_oracle(net)
     e_fast = sesrq.Engine(b, _dev(), engine=_lib.ENGINE_MFMA)
     e_exact = sesrq.Engine(b, _dev(), engine=_lib.ENGINE_MFMA, exact_division=True)
-    assert e_fast.fast_division_proven()
+    assert e_fast.fast_division_proven() and e_fast.layer_engines()[0].startswith("mfma-f5")
+    # the MFMA first-layer kernels carry only the proven form: with the division forced, layer 0 runs on the dot4 kernel
+    assert e_exact.fast_division_proven() and e_exact.layer_engines()[0].startswith("dot4") and \
+        e_exact.layer_engines()[1:] == e_fast.layer_engines()[1:]
     rng = np.random.default_rng(0)
     s0, z0 = np.float32(net.scale[0]), net.zero[0]
     x = rng.random((1, 3, 64, 96), dtype=np.float32)
@@ -221,6 +224,37 @@ def test_fast_division_is_proven_and_equals_exact_division():
     for tag in ("sesr_x4", "nrdm_3", "sesr_x2_rand"):
         fx, meta, gnet, gx = fixture_case(os.path.join(os.path.dirname(STAGE_FILES[0]), f"{tag}.crop.npz"))
         assert sesrq.Engine(bundle_from_oracle(gnet), _dev()).fast_division_proven(), tag
+
+
+def test_reciprocal_division_option_is_the_gpu_run_reference_quantiser():
+    """sesrq_options.exact_div = 2: x * fl(1/s0) instead of the quotient (what torch evaluates for tensor / scalar on a GPU,
+    where the reference's scripts run).  PARITY UNPINNED w.r.t. the reference (its goldens are CPU runs): every first-layer
+    kernel vs the numpy restatement, q0 within one LSB of the default quantiser's and different from it on some tie."""
+    net = O.synth_net("sesr_x2", 1)
+    net.scale[0] = 0.0039            # the synthetic 1/255 has fl(1/s0) == 255: both forms agree on every tie; this one does not
+    b = bundle_from_oracle(net)
+    s0, z0 = np.float32(net.scale[0]), net.zero[0]
+    rng = np.random.default_rng(5)
+    x = rng.random((1, 3, 40, 300), dtype=np.float32)
+    k = rng.integers(-128, 127, size=(3, 39, 300))
+    x[0, :, 1:, :] = ((k + 0.5 - z0) * float(s0)).astype(np.float32)                 # x/s + z at k + .5, to an ulp
+    q0d, q0r = O.quantize_input(x, s0, z0), O.quantize_input(x, s0, z0, reciprocal=True)
+    d = q0r.astype(int) - q0d.astype(int)
+    assert np.abs(d).max() == 1 and 0 < np.count_nonzero(d) < d.size // 2 and not d[0, :, 0].any()   # ties only
+    xt = torch.from_numpy(x).to(_dev())
+    ref = sesrq.Engine(b, _dev())
+    want_q, _ = ref.forward(torch.from_numpy(q0r).to(_dev()))                       # an int8 frame IS q0 (test_int8_input_path)
+    base_q, _ = ref.forward(xt)
+    assert not torch.equal(want_q, base_q)
+    for kw in (dict(engine=_lib.ENGINE_DOT4), dict(fuse_hidden=0), dict(fuse_hidden=1), dict(fuse_hidden=2)):
+        e = sesrq.Engine(b, _dev(), reciprocal_division=True, **kw)
+        assert e.fast_division_proven()                                             # the proof is reported whatever form runs
+        if kw.get("engine") == _lib.ENGINE_DOT4:
+            _cmp("q0 (input.0 tap)", e.forward_debug(xt, pe=False)["input0"], q0r)
+        q, _ = e.forward(xt)
+        assert torch.equal(q, want_q), kw
+    with pytest.raises(ValueError, match="exclude"):
+        sesrq.Engine(b, _dev(), reciprocal_division=True, exact_division=True)
 
 
 @pytest.mark.parametrize("layer,arch", [(0, "sesr_x2"), (1, "sesr_x2"), (3, "sesr_x2"), (4, "sesr_x4"), (4, "sesr_x2"), (4, "nrdm")])
@@ -391,7 +425,7 @@ def test_randomised_shapes_against_c_oracle():
             w = (net.layers[k].wq.astype(np.int32) // 2).astype(np.int8)
             w[int(rng.integers(w.shape[0])), int(rng.integers(min(4, w.shape[1])))::4] = 127
             net.layers[k].wq = w
-        e = sesrq.Engine(bundle_from_oracle(net), _dev())
+        e = sesrq.Engine(bundle_from_oracle(net), _dev(), fuse_hidden=1 + trial % 2)      # launch plans alternate: trio / fused front
         H, W, N = int(rng.choice(heights)), int(rng.choice(widths)), int(rng.choice([1, 1, 2, 3]))
         x = rng.random((N, net.layers[0].wq.shape[1], H, W), dtype=np.float32)
         want = CO.forward(net, x)
