@@ -530,8 +530,11 @@ __global__ __launch_bounds__(256) void mfma_h5p_kernel(const ConvArgs a) {
 // a pixel is one dword (byte c = channel c).  A lane's 16 bytes = 4 horizontally adjacent pixels
 // starting at an arbitrary pixel column: read as dwords (ds_read2_b32 pairs), which have no 16-byte
 // alignment requirement -- one copy of the tile in LDS, one ds_write_b32 per staged pixel.
-template <int SRC, int SH, int SWP, int PITCH>
+// NCH: input channels as a compile-time count (1 and 3 are the reference's nets), or 4 = "a.ic of them, tested per channel":
+// the wave-uniform test put every channel's load and quantise code into a block of its own.
+template <int SRC, int SH, int SWP, int PITCH, int NCH>
 struct StageFrame {
+    __device__ __forceinline__ static bool has_channel(const ConvArgs &a, int c) { return NCH < 4 ? c < NCH : c < a.ic; }
     static constexpr int NIT = (SH * SWP + 255) / 256;
     static constexpr int ESZ = (SRC == SRC_F32) ? 4 : 1;
     unsigned raw[NIT][4];
@@ -566,7 +569,7 @@ struct StageFrame {
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 raw[it][c] = 0;
-                if (c < a.ic) {            // wave-uniform: channel planes beyond ic are not loaded at all
+                if (has_channel(a, c)) {   // channel planes beyond ic are not loaded at all
                     const int so = (FIRST ? 0 : soff) + c * plane_bytes;
                     if constexpr (SRC == SRC_F32) raw[it][c] = __builtin_amdgcn_raw_buffer_load_b32(rs, vo, so, 0);
                     else raw[it][c] = (unsigned)(int)(signed char)__builtin_amdgcn_raw_buffer_load_b8(rs, vo, so, 0);
@@ -590,7 +593,7 @@ struct StageFrame {
                     b[c] = quantize_in_bits(__fmul_rn((float)(int)raw[it][c] - a.z_prev, a.s_prev), a.s_in, a.z_in, a.fd);
                 else
                     b[c] = raw[it][c];
-                if (c >= a.ic) b[c] = 0;
+                if (!has_channel(a, c)) b[c] = 0;
             }
             int word = (int)pack_lo_bytes(b[0], b[1], b[2], b[3]);
             if (!ok[it]) word = a.pad_word;
@@ -607,7 +610,7 @@ constexpr int F5_SH = F5_TH + 4;
 constexpr int F5_SWP = MTW + 8;         // staged pixel columns (2 halo + 64 + 2 halo + over-read)
 constexpr int F5_PITCH = F5_SWP + 8;    // LDS row pitch in pixels: 16 dwords mod 32, so the four lane groups of an
                                         // operand read (rows g, g+1, ...) hit disjoint banks
-template <int MODE, int SRC, bool RC>
+template <int MODE, int SRC, bool RC, int NCH>
 __device__ __forceinline__ void mfma_f5_body(const ConvArgs &a, int4 *buf0, int4 *buf1) {
     constexpr bool GENERAL = MODE == GEN_STD || MODE == GEN_ANY;
     constexpr int SH = F5_SH, SWP = F5_SWP, PITCH = F5_PITCH;
@@ -673,7 +676,7 @@ __device__ __forceinline__ void mfma_f5_body(const ConvArgs &a, int4 *buf0, int4
         }
     };
 #define SESRQ_COMPUTE(B) compute(B, y0);
-    using Stage = StageFrame<SRC, SH, SWP, PITCH>;
+    using Stage = StageFrame<SRC, SH, SWP, PITCH, NCH>;
     SESRQ_TILE_WALK_H(F5_TH, Stage, buf0, buf1, SESRQ_COMPUTE)
 #undef SESRQ_COMPUTE
 }
@@ -682,15 +685,15 @@ __device__ __forceinline__ void mfma_f5_body(const ConvArgs &a, int4 *buf0, int4
 // NOT for the per-PE (general) variants: squeezed to 128 VGPRs, hipcc 7.2 produced a GEN_STD + residual-tensor instance whose
 // first output word was garbage in lanes 28..31 (caught by the satw_zeros golden vectors; the same source without the
 // attribute, or with unrelated extra code in the loop, is correct) -- those take the registers they ask for.
-template <int MODE, int SRC, bool RC>
+template <int MODE, int SRC, bool RC, int NCH>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void mfma_f5_kernel_w4(const ConvArgs a) {
     __shared__ int4 buf0[F5_SH * F5_PITCH / 4], buf1[F5_SH * F5_PITCH / 4];      // SH rows of 4-byte pixels
-    mfma_f5_body<MODE, SRC, RC>(a, buf0, buf1);
+    mfma_f5_body<MODE, SRC, RC, NCH>(a, buf0, buf1);
 }
-template <int MODE, int SRC, bool RC>
+template <int MODE, int SRC, bool RC, int NCH>
 __global__ __launch_bounds__(256) void mfma_f5_kernel(const ConvArgs a) {
     __shared__ int4 buf0[F5_SH * F5_PITCH / 4], buf1[F5_SH * F5_PITCH / 4];
-    mfma_f5_body<MODE, SRC, RC>(a, buf0, buf1);
+    mfma_f5_body<MODE, SRC, RC, NCH>(a, buf0, buf1);
 }
 
 #ifdef SESRQ_STAMPS
@@ -777,9 +780,16 @@ int launch_mfma(const LayerPlan &lp, const ConvArgs &a_in, int src, int epi, boo
         else if (mode == GEN_STD) launch(mfma_f5_kernel<GEN_STD, __VA_ARGS__>, a, st, F5_TH);   \
         else launch(mfma_f5_kernel<GEN_ANY, __VA_ARGS__>, a, st, F5_TH);                        \
     } while (0)
-            if (src == SRC_F32) { if (a.rc_out) SESRQ_F5(SRC_F32, true); else SESRQ_F5(SRC_F32, false); }
-            else if (src == SRC_I8D) { if (a.rc_out) SESRQ_F5(SRC_I8D, true); else SESRQ_F5(SRC_I8D, false); }
-            else { if (a.rc_out) SESRQ_F5(SRC_I8, true); else SESRQ_F5(SRC_I8, false); }
+#define SESRQ_F5_NCH(...)                                                      \
+    do {                                                                       \
+        if (a.ic == 3) SESRQ_F5(__VA_ARGS__, 3);                               \
+        else if (a.ic == 1) SESRQ_F5(__VA_ARGS__, 1);                          \
+        else SESRQ_F5(__VA_ARGS__, 4);                                         \
+    } while (0)
+            if (src == SRC_F32) { if (a.rc_out) SESRQ_F5_NCH(SRC_F32, true); else SESRQ_F5_NCH(SRC_F32, false); }
+            else if (src == SRC_I8D) { if (a.rc_out) SESRQ_F5_NCH(SRC_I8D, true); else SESRQ_F5_NCH(SRC_I8D, false); }
+            else { if (a.rc_out) SESRQ_F5_NCH(SRC_I8, true); else SESRQ_F5_NCH(SRC_I8, false); }
+#undef SESRQ_F5_NCH
 #undef SESRQ_F5
             break;
         default: set_error("mfma: layer shape not supported by the MFMA engine"); return 1;

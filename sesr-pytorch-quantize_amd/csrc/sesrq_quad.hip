@@ -39,8 +39,9 @@ constexpr int Q_ACC_I4 = 3 * 4;                                           // the
 constexpr int QUAD_LDS_BYTES = (Q_WIN_I + 2 * Q_WIN + Q_RAW_I4 + Q_FRAG_I4 + Q_ACC_I4) * 16;      // 40 960 B: four workgroups per CU
 
 // RAW staging: the frame's pixels of 8 (cold: 12) rows x 72 columns, quantised to one dword each
-template <int SRC>
+template <int SRC, int NCH>       // NCH: channels as a compile-time count (1, 3), or 4 = a.ic tested per channel (StageFrame)
 struct QuadStage {
+    __device__ __forceinline__ static bool has_channel(const QuadArgs &a, int c) { return NCH < 4 ? c < NCH : c < a.ic; }
     static constexpr int NIT_COLD = (QRR * QRC + 255) / 256;      // 4
     static constexpr int NIT = (TH * QRC + 255) / 256;            // 3
     static constexpr int ESZ = (SRC == SRC_F32) ? 4 : 1;
@@ -80,7 +81,7 @@ struct QuadStage {
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 unsigned v = 0;
-                if (c < a.ic) {            // wave-uniform: channel planes beyond ic are not loaded at all
+                if (has_channel(a, c)) {   // channel planes beyond ic are not loaded at all
                     const int so = (COLD ? 0 : soff) + c * plane_bytes;
                     if constexpr (SRC == SRC_F32) v = __builtin_amdgcn_raw_buffer_load_b32(rs, vo, so, 0);
                     else v = (unsigned)(int)(signed char)__builtin_amdgcn_raw_buffer_load_b8(rs, vo, so, 0);
@@ -103,7 +104,7 @@ struct QuadStage {
                 if constexpr (SRC == SRC_F32) b[c] = quantize_in_bits(__builtin_bit_cast(float, rv), a.s_in, a.z_in, a.fd);
                 else if constexpr (SRC == SRC_I8D) b[c] = quantize_in_bits(__fmul_rn((float)(int)rv - a.z_prev, a.s_prev), a.s_in, a.z_in, a.fd);
                 else b[c] = rv;
-                if (c >= a.ic) b[c] = 0;
+                if (!has_channel(a, c)) b[c] = 0;
             }
             int word = (int)pack_lo_bytes(b[0], b[1], b[2], b[3]);
             if (!ok[it]) word = a.pad_raw;
@@ -120,7 +121,7 @@ struct QuadEpi0 {
     int acc_lo, acc_hi, add_lo, add_hi;      // unused (merged / hybrid first layer); finish_sums' generic branch names them
 };
 
-template <int MODE0, int SRC>
+template <int MODE0, int SRC, int NCH>
 __global__ __launch_bounds__(256) void mfma_quad_kernel(const QuadArgs a) {
     extern __shared__ int4 quad_lds[];
     int4 *bufI = quad_lds, *bufA = bufI + Q_WIN_I, *bufB = bufA + Q_WIN;
@@ -290,7 +291,7 @@ __global__ __launch_bounds__(256) void mfma_quad_kernel(const QuadArgs a) {
         if (tid < 3 * TP) { const int4 t = bufI[TH * TP + tid]; bufI[tid] = t; }
     };
 
-    QuadStage<SRC> st;
+    QuadStage<SRC, NCH> st;
     st.init(a, n_img, x0, tid);
     const int shl0 = (tid / QRC) * QRP + tid % QRC, shl1 = ((tid + 256) / QRC) * QRP + (tid + 256) % QRC;     // RAW shift: 4 rows x 72 dwords
     // one step; COLD: the step before the run's first one (RAW loaded whole, 4 / 2 rows of the inner layers, nothing stored)
@@ -363,14 +364,21 @@ static void launch_quad_k(K kern, QuadArgs a, hipStream_t st) {
 int launch_quad(const QuadArgs &a, bool hybrid, int src, hipStream_t st) {
     static_assert(QUAD_LDS_BYTES <= 40960, "four workgroups per CU");
     if ((size_t)a.t.H * a.t.W * 16 >= ((size_t)1 << 28)) { set_error("quad: frame too large for 32-bit buffer offsets (H*W must stay below 2^24 pixels)"); return 1; }
-#define SESRQ_QUAD(SRC_)                                                       \
-    do {                                                                       \
-        if (hybrid) launch_quad_k(mfma_quad_kernel<HYB, SRC_>, a, st);         \
-        else launch_quad_k(mfma_quad_kernel<MERGED, SRC_>, a, st);             \
+#define SESRQ_QUAD(SRC_, NCH_)                                                     \
+    do {                                                                           \
+        if (hybrid) launch_quad_k(mfma_quad_kernel<HYB, SRC_, NCH_>, a, st);       \
+        else launch_quad_k(mfma_quad_kernel<MERGED, SRC_, NCH_>, a, st);           \
     } while (0)
-    if (src == SRC_F32) SESRQ_QUAD(SRC_F32);
-    else if (src == SRC_I8D) SESRQ_QUAD(SRC_I8D);
-    else SESRQ_QUAD(SRC_I8);
+#define SESRQ_QUAD_NCH(SRC_)                                                       \
+    do {                                                                           \
+        if (a.ic == 3) SESRQ_QUAD(SRC_, 3);                                        \
+        else if (a.ic == 1) SESRQ_QUAD(SRC_, 1);                                   \
+        else SESRQ_QUAD(SRC_, 4);                                                  \
+    } while (0)
+    if (src == SRC_F32) SESRQ_QUAD_NCH(SRC_F32);
+    else if (src == SRC_I8D) SESRQ_QUAD_NCH(SRC_I8D);
+    else SESRQ_QUAD_NCH(SRC_I8);
+#undef SESRQ_QUAD_NCH
 #undef SESRQ_QUAD
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { set_error(std::string("quad launch failed: ") + hipGetErrorString(e)); return 1; }
