@@ -83,8 +83,8 @@ struct LastStore {
         }
     }
     // gy: wave-uniform row; row_ok: false drops this lane's stores (lanes whose own row gy + lane_row is below the frame)
-    // FAST = 2 / 4: PixelShuffle factor known at compile time, int8 output only, every row valid (the call sites test the
-    // row): no output-kind / shuffle-factor branches and no per-row offset selects in the hot loop of the SESR last layer
+    // FAST = 2 / 4: PixelShuffle factor known at compile time, int8 output only, row_ok wave-uniform: no output-kind /
+    // shuffle-factor / row branches and no per-row offset selects in the hot loop of the SESR last layer
     template <bool BIASED, int FAST = 0>
     __device__ __forceinline__ void store(const int s[4], const ConvArgs &a, int gy, float zlo, bool row_ok = true) const {
         v2f v01, v23;
@@ -92,7 +92,12 @@ struct LastStore {
         const v2f mg = {MAGIC, MAGIC};
         v2f c01 = {med3(v01[0], zlo, 127.f), med3(v01[1], zlo, 127.f)}, c23 = {med3(v23[0], zlo, 127.f), med3(v23[1], zlo, 127.f)};
         c01 = c01 + mg; c23 = c23 + mg;                    // low mantissa bits = rint(value), two's complement
-        const int so = gy * row_elems;
+        // scalar offset of the row: gy is wave-uniform by contract, but derives from threadIdx (the wave index), so the
+        // compiler must be TOLD -- the GEN_STD last layer otherwise wraps every store in a waterfall loop (readfirstlane /
+        // compare / saveexec / branch), which also keeps a row's stores from overlapping the next row's MFMA chain
+        // FAST: row_ok is wave-uniform too (the whole row is inside the frame or not); a row outside gets an offset the
+        // buffer's range check rejects (it adds voffset + soffset in wide arithmetic, tools/oob_probe.hip)
+        const int so = __builtin_amdgcn_readfirstlane((FAST == 0 || row_ok) ? gy * row_elems : 0x7fff0000);
         if constexpr (FAST != 0) {
             const unsigned w = pack_lo_bytes(fbits(c01[0]), fbits(c01[1]), fbits(c23[0]), fbits(c23[1]));
             if constexpr (FAST == 2) {
@@ -402,7 +407,8 @@ __global__ __launch_bounds__(256) void mfma_h5_kernel(const ConvArgs a) {
                     }
                     finish_sums<MODE>(s4[r], acc, ac, a);
                     if constexpr (EPI == EPI_LAST) {
-                        if (y0 + y < a.H) ls.store<BIASED, FAST>(s4[r], a, y0 + y, zlo);
+                        // FAST: a row below the frame is dropped by the scalar offset, not by a branch (four rows stay one block)
+                        if (FAST != 0 || y0 + y < a.H) ls.store<BIASED, FAST>(s4[r], a, y0 + y, zlo, y0 + y < a.H);
                     }
                 }
                 if constexpr (EPI != EPI_LAST) emit_rows4<EPI, false, BIASED>(s4, a, io, y4, zlo);
@@ -430,7 +436,8 @@ __global__ __launch_bounds__(256) void mfma_h5_kernel(const ConvArgs a) {
                     }
                     finish_sums<MODE>(s4[r], acc, ac, a);
                     if constexpr (EPI == EPI_LAST) {
-                        if (y0 + y < a.H) ls.store<BIASED, FAST>(s4[r], a, y0 + y, zlo);
+                        // FAST: a row below the frame is dropped by the scalar offset, not by a branch (four rows stay one block)
+                        if (FAST != 0 || y0 + y < a.H) ls.store<BIASED, FAST>(s4[r], a, y0 + y, zlo, y0 + y < a.H);
                     }
                 }
                 if constexpr (EPI != EPI_LAST) emit_rows4<EPI, false, BIASED>(s4, a, io, y4, zlo);
