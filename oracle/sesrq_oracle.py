@@ -155,7 +155,8 @@ def quantize_input(x: np.ndarray, s0: float, z0: int, reciprocal: bool = False) 
     reciprocal=True: x * f32(1 / f32(s0)) instead of the quotient -- how torch evaluates tensor / scalar on a GPU, where
     the reference's scripts run; no fixture pins it (the goldens come from a CPU run)."""
     x = np.asarray(x, F32)
-    t = x * (F32(1) / F32(s0)) if reciprocal else x / F32(s0)
+    with np.errstate(over="ignore"):          # huge x / s0 -> inf -> clamps to +-127 like in the reference
+        t = x * (F32(1) / F32(s0)) if reciprocal else x / F32(s0)
     return np.clip(np.rint(t + F32(z0)), -128, 127).astype(np.int8)
 
 

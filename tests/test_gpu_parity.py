@@ -194,6 +194,20 @@ def test_error_conventions():
     bad.pe_num = 8
     with pytest.raises(ValueError, match="pe_num"):
         sesrq.Engine(bad, _dev())
+    # option values outside their range are refused by sesrq_create (the net would otherwise be built on a guess)
+    for kw, msg in ((dict(fuse_hidden=3), "fuse_hidden"), (dict(fuse_hidden=-1), "fuse_hidden"), (dict(engine=9), "engine")):
+        with pytest.raises(ValueError, match=msg):
+            sesrq.Engine(b, _dev(), **kw)
+    # a scale the reciprocal form cannot represent (1/s0 overflows): exact_div = 2 is refused, the default falls back to the
+    # division (first layer on the dot4 kernel) and still matches the oracle
+    tiny = O.synth_net("nrdm", 0)
+    tiny.scale[0] = 1e-39
+    with pytest.raises(ValueError, match="exact_div = 2"):
+        sesrq.Engine(bundle_from_oracle(tiny), _dev(), reciprocal_division=True)
+    et = sesrq.Engine(bundle_from_oracle(tiny), _dev())
+    assert not et.fast_division_proven() and et.layer_engines()[0].startswith("dot4")
+    x = rand_frame((1, 3, 9, 21), 2) * np.float32(2e-37)
+    _cmp("unproven scale: division on the dot4 kernel", et.forward(torch.from_numpy(x).to(_dev()))[0], O.forward(tiny, x)["q_out"])
 
 
 def test_fast_division_is_proven_and_equals_exact_division():
