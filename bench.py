@@ -220,7 +220,7 @@ def main():
         fps = args.steps * total_frames_per_step / elapsed_med
         fps_all = sorted(args.steps * total_frames_per_step / e for e in res["elapsed"])
         px = B * H * W
-        # ---- roofline per launch: HIP events on the launch stream, inside this process (first net of a chain)
+        # ---- roofline per launch: begin/end HIP events of every kernel on the launch stream, inside this process (first net of a chain)
         eng, bundle = engines[0], bundles[0]
         plan = eng.launch_plan()
         alg = [launch_bytes_per_px(bundle, f, c, True) * px for f, c in plan]
@@ -246,7 +246,8 @@ def main():
                     "bytes_per_frame": {"as_launched": per_frame_fused, "layer_by_layer": per_frame_layerwise},
                     "throughput_frac": round(per_frame_fused * fps / world / HBM_PEAK, 4),
                     "layerwise_frac": round(per_frame_layerwise * fps / world / HBM_PEAK, 4),
-                    "note": "launches[].ms: HIP events around each launch on one stream (sesrq_forward_timed); alg_bytes: what the "
+                    "note": "launches[].ms: begin/end HIP events of each kernel on the launch stream (hipExtLaunchKernelGGL inside sesrq_forward_timed: the "
+                            "duration a rocprofv3 kernel trace reports); forward_device_ms: begin of the first to end of the last kernel; alg_bytes: what the "
                             "launch must move (DESIGN 4.4; a fused trio moves 48 B/px, not its layers' 112); layerwise_frac = SURVEY "
                             "8(d)'s layer-by-layer bytes per frame x frames/s/GPU / peak = the north star's HBM-roofline fraction"}
 

@@ -149,10 +149,12 @@ int sesrq_forward_debug(const sesrq_net *net, const void *in, int in_dtype, void
  * (count 3 = fused hidden trio, 4 = first layer + trio).  Returns the number of launches (<= n_layers); first/count may be NULL. */
 int sesrq_launch_plan(const sesrq_net *net, int *first, int *count);
 
-/* Measurement hook: runs `iters` forwards back to back on `stream` with a HIP event pair around
- * every launch (events recorded on the same stream as the kernels), synchronises once at
- * the end and returns the AVERAGE device time per launch in launch_ms[0..sesrq_launch_plan()-1] (ms) and the
- * average time of a whole forward in *forward_ms.  Not part of the hot path. */
+/* Measurement hook: runs `iters` forwards back to back on `stream`, every kernel launched with its own begin / end
+ * HIP events (hipExtLaunchKernelGGL: the timestamps of the dispatch itself -- the duration a rocprofv3 kernel trace
+ * reports for it, without the dispatch latency a hipEventRecord pair around the launch would add), synchronises once
+ * at the end and returns the AVERAGE device time per launch in launch_ms[0..sesrq_launch_plan()-1] (ms) and the
+ * average time from the begin of the first to the end of the last kernel of a forward in *forward_ms.  Not part of
+ * the hot path. */
 int sesrq_forward_timed(const sesrq_net *net, const void *in, int in_dtype, void *out_q, void *out_f,
                         int N, int H, int W, void *workspace, size_t workspace_bytes, void *stream,
                         int iters, float *launch_ms, float *forward_ms);

@@ -10,6 +10,8 @@
 
 namespace sesrq {
 
+thread_local KernelEvents tl_kernel_events;
+
 static thread_local std::string g_err;
 void set_error(const std::string &msg) { g_err = msg; }
 
@@ -456,6 +458,7 @@ static int forward_impl(const sesrq_net *net, const void *in, int in_dtype, void
     void *bufRC = net->rc_separate ? (void *)(ws + wl.off_rc) : bufS;
     const void *cur = in;
     int launch = 0;
+    struct ClearKernelEvents { ~ClearKernelEvents() { tl_kernel_events = KernelEvents{}; } } clear_on_any_exit;
     for (int k = 0; k < L; ++launch) {
         const LayerPlan &lp = net->layers[k];
         if (k == 0 && quad_active(net, taps) && !(net->anchor_add && in_dtype != SESRQ_F32)) {
@@ -488,9 +491,9 @@ static int forward_impl(const sesrq_net *net, const void *in, int in_dtype, void
             q.s_prev = net->i8_in_scale; q.z_prev = (float)net->i8_in_zero;
             q.fd = net->fd;
             const int src = in_dtype == SESRQ_F32 ? SRC_F32 : (net->i8_in_scale > 0.f ? SRC_I8D : SRC_I8);
-            if (ev && hipEventRecord(ev[2 * launch], st) != hipSuccess) { set_error("hipEventRecord failed"); return 1; }
+            if (ev) tl_kernel_events = KernelEvents{ev[2 * launch], ev[2 * launch + 1]};     // begin / end events of the next kernel
             if (launch_quad(q, lp.general, src, st)) return 1;
-            if (ev && hipEventRecord(ev[2 * launch + 1], st) != hipSuccess) { set_error("hipEventRecord failed"); return 1; }
+            tl_kernel_events = KernelEvents{};
             cur = dst;
             k += 4;
             continue;
@@ -512,9 +515,9 @@ static int forward_impl(const sesrq_net *net, const void *in, int in_dtype, void
                 t.l[j].zlo = lj.base.relu ? fmaxf(lj.base.z_next, -128.f) : -128.f;
                 t.l[j].pad_next = net->layers[k + j + 1].base.pad_word;
             }
-            if (ev && hipEventRecord(ev[2 * launch], st) != hipSuccess) { set_error("hipEventRecord failed"); return 1; }
+            if (ev) tl_kernel_events = KernelEvents{ev[2 * launch], ev[2 * launch + 1]};     // begin / end events of the next kernel
             if (launch_trio(t, (k + 2 == L - 2) ? EPI_PRERES : EPI_MID, st)) return 1;
-            if (ev && hipEventRecord(ev[2 * launch + 1], st) != hipSuccess) { set_error("hipEventRecord failed"); return 1; }
+            tl_kernel_events = KernelEvents{};
             cur = dst;
             k += 3;
             continue;
@@ -548,7 +551,7 @@ static int forward_impl(const sesrq_net *net, const void *in, int in_dtype, void
                 set_error("sesrq_forward: debug unpack launch failed"); return 1;
             }
         }
-        if (ev && hipEventRecord(ev[2 * launch], st) != hipSuccess) { set_error("hipEventRecord failed"); return 1; }
+        if (ev) tl_kernel_events = KernelEvents{ev[2 * launch], ev[2 * launch + 1]};     // begin / end events of the next kernel
         const bool use_mfma = net->engine != SESRQ_ENGINE_DOT4 && lp.mfma_kind != MFMA_NONE && !dbg && !q0tap && (k > 0 || net->fd.ok);
         if (use_mfma) {
             a.afrag = eff.general ? lp.d_afrag_general : lp.d_afrag_merged;
@@ -558,7 +561,7 @@ static int forward_impl(const sesrq_net *net, const void *in, int in_dtype, void
             if (lp.d_afrag_pesplit) a.afrag = lp.d_afrag_pesplit;
             if (launch_mfma(lp, a, src, epi, eff.general, st, one_pe)) return 1;
         } else if (launch_dot4(eff, a, src, epi, st)) return 1;
-        if (ev && hipEventRecord(ev[2 * launch + 1], st) != hipSuccess) { set_error("hipEventRecord failed"); return 1; }
+        tl_kernel_events = KernelEvents{};
         cur = dst;
         ++k;
     }

@@ -1,6 +1,7 @@
 // Internal declarations shared by the sesrq translation units (not part of the C ABI).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 #include <string>
 #include <vector>
@@ -8,6 +9,17 @@
 #include "sesrq.h"
 
 namespace sesrq {
+
+// Measurement hook of sesrq_forward_timed: while start/stop are set (this thread), the next kernel launch of the forward carries
+// them as its begin / end events (hipExtLaunchKernelGGL: timestamps of the dispatch itself, what a rocprofv3 kernel trace
+// reports) instead of a hipEventRecord pair around it, which would add the dispatch latency of the launch to every interval.
+struct KernelEvents { hipEvent_t start = nullptr, stop = nullptr; };
+extern thread_local KernelEvents tl_kernel_events;
+template <typename K, typename A>
+inline void launch_kernel(K kern, dim3 grid, dim3 block, unsigned lds, hipStream_t st, const A &a) {
+    if (tl_kernel_events.start) hipExtLaunchKernelGGL(kern, grid, block, lds, st, tl_kernel_events.start, tl_kernel_events.stop, 0, a);
+    else hipLaunchKernelGGL(kern, grid, block, lds, st, a);
+}
 
 enum Epi { EPI_MID = 0, EPI_PRERES = 1, EPI_LAST = 2 };
 enum Src { SRC_NHWC16 = 0, SRC_F32 = 1, SRC_I8 = 2, SRC_I8D = 3 };   // I8D: int8 frame in an upstream net's output domain

@@ -234,7 +234,7 @@ int launch_unpack_nhwc16(const void *nhwc, signed char *nchw, int N, int C, int 
 template <int K, int IN_DW, bool GENERAL, int EPI, int OCP, int SRC>
 static void launch_one(const ConvArgs &a, hipStream_t st) {
     dim3 grid((a.W + TW - 1) / TW, (a.H + TH - 1) / TH, a.N);
-    hipLaunchKernelGGL((conv_dot4_kernel<K, IN_DW, GENERAL, EPI, OCP, SRC>), grid, dim3(256), 0, st, a);
+    launch_kernel(conv_dot4_kernel<K, IN_DW, GENERAL, EPI, OCP, SRC>, grid, dim3(256), 0, st, a);
 }
 
 template <int K, bool GENERAL>

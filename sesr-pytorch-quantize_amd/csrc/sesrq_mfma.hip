@@ -740,7 +740,7 @@ static void launch(K kern, ConvArgs a, hipStream_t st, int tile_h = MTH) {
     k = std::max(1LL, std::min<long long>(k, row_tiles));
     a.chunk_tiles = (int)((row_tiles + k - 1) / k);
     dim3 grid(strips, (int)k, a.N);
-    hipLaunchKernelGGL(kern, grid, dim3(256), 0, st, a);
+    launch_kernel(kern, grid, dim3(256), 0, st, a);
 }
 
 #define SESRQ_BY_MODE(KERN, ...)                                                         \

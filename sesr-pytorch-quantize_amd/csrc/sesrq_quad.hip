@@ -358,7 +358,7 @@ static void launch_quad_k(K kern, QuadArgs a, hipStream_t st) {
     long long k = (a.t.wg_budget > 0 ? (long long)a.t.wg_budget : (long long)occ * num_cu) / ((long long)strips * a.t.N);
     k = std::max(1LL, std::min<long long>(k, steps));
     dim3 grid(strips, (int)k, a.t.N);
-    hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, a);
+    launch_kernel(kern, grid, dim3(256), (unsigned)lds, st, a);
 }
 
 int launch_quad(const QuadArgs &a, bool hybrid, int src, hipStream_t st) {

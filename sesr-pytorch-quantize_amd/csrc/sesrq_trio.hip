@@ -245,7 +245,7 @@ static void launch_trio_k(K kern, TrioArgs a, hipStream_t st) {
     k = std::max(1LL, std::min<long long>(k, steps));
     a.chunk_steps = (int)((steps + k - 1) / k);
     dim3 grid(strips, (int)k, a.N);
-    hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, a);
+    launch_kernel(kern, grid, dim3(256), (unsigned)lds, st, a);
 }
 
 int launch_trio(const TrioArgs &a, int epi_c, hipStream_t st) {
