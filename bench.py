@@ -76,6 +76,8 @@ def main():
                          "(blocks_fps shows it: 12.2, 10.5, 10.3, 10.9, 11.7 ... 12.5 k frames/s for 20-step blocks), so five "
                          "20-step blocks (9 ms in all) would sit entirely inside that transient")
     ap.add_argument("--batch", type=int, default=0, help="frames per step per GPU (0 = the workload's own)")
+    ap.add_argument("--graph", action="store_true", help="replay each step as a captured HIP graph (Engine.capture): same kernels, one "
+                                                         "host call per step instead of one per launch")
     ap.add_argument("--streams", type=int, default=2,
                     help="HIP streams the steps are enqueued on round-robin (frames are independent; each stream has "
                          "its own workspace and output buffer) -- fills the launch/prologue/tail gaps between kernels")
@@ -154,10 +156,19 @@ def main():
             cur = outs[slot][j]
         return cur
 
+    graphs = {}
+    if args.graph and B > 0:       # one graph per (stream slot, pool frame): the input pointer is part of a graph
+        for slot in range(NS):
+            for j in range(POOL):
+                graphs[(slot, j)] = engines[0].capture(pool[j], want_q=True, want_f=False, slot=slot, downstream=engines[1:])
+
     def step():
         i = counter[0]
         counter[0] += 1
-        if B > 0:
+        if B > 0 and graphs:
+            with torch.cuda.stream(streams[i % NS]):
+                graphs[(i % NS, i % POOL)].replay()
+        elif B > 0:
             forward_chain(pool[i % POOL], i % NS, streams[i % NS])
 
     # ---- before the timed region (rank 0): parity of a whole frame against the C oracle (doubles as the CPU baseline), then
@@ -263,7 +274,7 @@ def main():
                   "vs_baseline": None, "dtype": "i8", "data": "synthetic",
                   "host_enqueue_us_per_step": None if res["host_enqueue_s_per_step"] is None else round(res["host_enqueue_s_per_step"] * 1e6, 1), "repeats": args.repeats, "blocks_fps": [round(args.steps * total_frames_per_step / e, 1) for e in res["elapsed"]], "spread": {"min": round(fps_all[0], 2), "median": round(fps, 2), "max": round(fps_all[-1], 2)},
                   "config": {"workload": desc, "name": args.workload, "frames_per_step_per_gpu": B, "frames_per_step": total_frames_per_step,
-                             "streams": NS, "input_pool": f"{POOL} distinct resident frames, rotated per step",
+                             "streams": NS, "hip_graph": bool(graphs), "input_pool": f"{POOL} distinct resident frames, rotated per step",
                              "in": [B, cin, H, W], "out": list(shapes[-1]), "input_dtype": "f32", "output_dtype": "i8",
                              "weights": [("reference random-init net, calibrated by the reference" if "rand" in f else
                                           "reference checkpoint, calibrated by this package (parity unpinned)" if "bundle" in f else

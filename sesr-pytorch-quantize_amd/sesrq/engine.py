@@ -12,6 +12,53 @@ from . import _lib
 from .bundle import Bundle
 
 
+class GraphedForward:
+    """A forward (or a chain of forwards: nrdm_6 -> SESR-x2) captured as a HIP graph (Engine.capture)."""
+
+    def __init__(self, engine, x, want_q, want_f, slot, downstream):
+        if downstream and not want_q:
+            raise ValueError("a chain hands the int8 output on: want_q must be True")
+        dt = engine._check_in(x)
+        del dt
+        if not x.is_contiguous():
+            raise ValueError("capture needs a contiguous input buffer (it is baked into the graph)")
+        self.engines = (engine,) + downstream
+        self.x = x
+        dev = engine.device
+        N, _, H, W = x.shape
+        self.outs = []
+        cur_shape = (N, H, W)
+        for j, e in enumerate(self.engines):
+            shp = e.out_shape(*cur_shape)
+            last = j == len(self.engines) - 1
+            q = torch.empty(shp, dtype=torch.int8, device=dev) if (want_q or not last) else None
+            y = torch.empty(shp, dtype=torch.float32, device=dev) if (want_f and last) else None
+            self.outs.append((q, y))
+            e.workspace(*cur_shape, slot)                 # allocate outside the capture
+            cur_shape = (shp[0], shp[2], shp[3])
+        self.q, self.y = self.outs[-1]
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            self._issue(side, slot)                       # warm-up: one-time occupancy queries / attribute calls happen here
+        torch.cuda.current_stream(dev).wait_stream(side)
+        torch.cuda.synchronize(dev)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph, stream=side):
+            self._issue(side, slot)
+
+    def _issue(self, stream, slot):
+        cur = self.x
+        for e, (q, y) in zip(self.engines, self.outs):
+            e.forward(cur, want_q=q is not None, want_f=y is not None, out_q=q, out_f=y, stream=stream, slot=slot,
+                      assume_ordered=True)
+            cur = q
+
+    def replay(self):
+        self.graph.replay()
+        return self.q, self.y
+
+
 class Engine:
     """One immutable net on one device.  forward() is stream-ordered and allocation-free once
     the workspace for a given (N, H, W) exists."""
@@ -168,6 +215,13 @@ class Engine:
         return out_q, out_f
 
     __call__ = forward
+
+    def capture(self, x: torch.Tensor, want_q: bool = True, want_f: bool = False, slot: int = 0, downstream=()):
+        """Capture one forward on `x` (and then, optionally, the chained `downstream` engines on its int8 output) as a HIP
+        graph.  Returns a GraphedForward: `.replay()` re-issues the kernels on the current stream with ONE host call
+        (x, q, y are fixed buffers: overwrite x in place -- stream-ordered -- to process another frame).  The kernels and
+        their results are exactly those of forward(); what changes is the host cost per frame."""
+        return GraphedForward(self, x, want_q, want_f, slot, tuple(downstream))
 
     def forward_timed(self, x: torch.Tensor, iters: int = 10):
         """Measurement hook (sesrq_forward_timed): average device ms per kernel launch (see launch_plan())

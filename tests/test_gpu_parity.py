@@ -586,6 +586,41 @@ def test_side_stream_with_non_contiguous_input():
     _cmp("y", y, want["y"])
 
 
+def test_captured_graph_replays_the_same_bits():
+    """Engine.capture: the forward (and a two-net chain) as a HIP graph -- same kernels, so the same bytes as the eager call;
+    a new frame written into the captured input buffer is what the next replay processes."""
+    net = O.synth_net("sesr_x2", 3)
+    e = sesrq.Engine(bundle_from_oracle(net), _dev())
+    x = torch.from_numpy(rand_frame((2, 3, 37, 150), 1)).to(_dev())
+    g = e.capture(x, want_q=True, want_f=True)
+    q0, y0 = e.forward(x)
+    q, y = g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(q, q0) and torch.equal(y, y0)
+    x2 = rand_frame((2, 3, 37, 150), 2)
+    x.copy_(torch.from_numpy(x2))
+    q, _ = g.replay()
+    _cmp("graph replay on a new frame", q, O.forward(net, x2)["q_out"])
+    side = torch.cuda.Stream(device=_dev())
+    side.wait_stream(torch.cuda.current_stream(_dev()))
+    with torch.cuda.stream(side):
+        q, _ = g.replay()                                  # on another stream
+    side.synchronize()
+    _cmp("graph replay on a side stream", q, O.forward(net, x2)["q_out"])
+    # chain: nrdm_6 -> SESR-x2 with the int8 hand-off, one graph
+    nr = O.synth_net("nrdm", 21, n_blocks=6)
+    e1 = sesrq.Engine(bundle_from_oracle(nr), _dev())
+    e2 = sesrq.Engine(bundle_from_oracle(net), _dev(), upstream=bundle_from_oracle(nr))
+    xc = torch.from_numpy(rand_frame((1, 3, 30, 70), 4)).to(_dev())
+    gc = e1.capture(xc, downstream=[e2])
+    qa, _ = e2.forward(e1.forward(xc, want_f=False)[0], want_f=False)
+    qb, _ = gc.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(qa, qb) and tuple(qb.shape) == (1, 3, 60, 140)
+    with pytest.raises(ValueError, match="contiguous"):
+        e.capture(x[:, :, :, ::2])
+
+
 def test_overflow_counters_mirror_the_reference_prints():
     """sesrq_taps.overflow counts PE sums outside the 18-bit accumulator range before saturation -- the events the
     reference prints as max_overflow / min_overflow (myQL/quan_func.py:358-361); golden: the saturating-weight
