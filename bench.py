@@ -34,7 +34,8 @@ POOL = 8                     # distinct resident input frames the steps rotate o
 WORKLOADS = {
     "sesr_x2_1080p": (["sesr_x2_rand.crop.npz"], 3, 1080, 1920, ("per_gpu", 1),
                       "SESR-x2 INT8 1080p->4K (3->12ch, PixelShuffle 2)"),                       # BASELINE config 2 (headline)
-    "nrdm_3_540p": (["nrdm_3.crop.npz"], 3, 540, 960, ("per_gpu", 1), "nrdm_3 INT8 960x540 denoise+demosaic (3->3ch)"),   # config 3
+    "nrdm_3_540p": (["nrdm_3_qat.crop.npz"], 3, 540, 960, ("per_gpu", 1),
+                    "nrdm_3 INT8 (nrdm_3_qat_G.pth) 960x540 denoise+demosaic (3->3ch)"),          # config 3 (the QAT checkpoint it names)
     "sesr_x4_540p": (["sesr_x4.crop.npz"], 1, 540, 960, ("per_gpu", 1), "SESR-x4 INT8 540p->4K (1->16ch, PixelShuffle 4)"),
     "sesr_x4_540p_b32": (["sesr_x4.crop.npz"], 1, 540, 960, ("total", 32),
                          "SESR-x4 INT8 540p->4K, batch of 32 frames sharded over the ranks"),   # config 4

@@ -407,8 +407,9 @@ __global__ __launch_bounds__(256) void mfma_h5_kernel(const ConvArgs a) {
                     }
                     finish_sums<MODE>(s4[r], acc, ac, a);
                     if constexpr (EPI == EPI_LAST) {
-                        // FAST: a row below the frame is dropped by the scalar offset, not by a branch (four rows stay one block)
-                        if (FAST != 0 || y0 + y < a.H) ls.store<BIASED, FAST>(s4[r], a, y0 + y, zlo, y0 + y < a.H);
+                        // a row below the frame is dropped by its offsets (FAST: the scalar one, else the lanes'), not by a
+                        // branch: the four rows stay one basic block
+                        ls.store<BIASED, FAST>(s4[r], a, y0 + y, zlo, y0 + y < a.H);
                     }
                 }
                 if constexpr (EPI != EPI_LAST) emit_rows4<EPI, false, BIASED>(s4, a, io, y4, zlo);
@@ -436,8 +437,9 @@ __global__ __launch_bounds__(256) void mfma_h5_kernel(const ConvArgs a) {
                     }
                     finish_sums<MODE>(s4[r], acc, ac, a);
                     if constexpr (EPI == EPI_LAST) {
-                        // FAST: a row below the frame is dropped by the scalar offset, not by a branch (four rows stay one block)
-                        if (FAST != 0 || y0 + y < a.H) ls.store<BIASED, FAST>(s4[r], a, y0 + y, zlo, y0 + y < a.H);
+                        // a row below the frame is dropped by its offsets (FAST: the scalar one, else the lanes'), not by a
+                        // branch: the four rows stay one basic block
+                        ls.store<BIASED, FAST>(s4[r], a, y0 + y, zlo, y0 + y < a.H);
                     }
                 }
                 if constexpr (EPI != EPI_LAST) emit_rows4<EPI, false, BIASED>(s4, a, io, y4, zlo);

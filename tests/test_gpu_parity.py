@@ -555,7 +555,9 @@ def test_config2_full_frame_1080p_on_the_timed_kernels():
 
 
 def test_config3_full_frame_nrdm3_540p():
-    """BASELINE config 3: nrdm_3 (reference checkpoint, reference calibration) 1x3x540x960, whole frame."""
+    """BASELINE config 3: nrdm_3 (reference checkpoints -- nrdm_3_qat_G.pth, the one config 3 names, and nrdm_3_raw_G.pth --
+    reference calibration) 1x3x540x960, whole frame."""
+    _full_frame_case("nrdm_3_qat.crop.npz", (1, 3, 540, 960), 3, ["mfma-f5-merged"] + ["mfma-trio-merged"] * 3 + ["mfma-h5p-general"])
     _full_frame_case("nrdm_3.crop.npz", (1, 3, 540, 960), 3, ["mfma-f5-merged"] + ["mfma-trio-merged"] * 3 + ["mfma-h5p-merged"])
     _full_frame_case("nrdm_3.crop.npz", (1, 3, 540, 960), 3, ["mfma-quad-merged"] * 4 + ["mfma-h5p-merged"], fuse_hidden=2)
 
