@@ -178,6 +178,33 @@ def test_full_size_properties_1080p():
     assert torch.equal(qb[0:1], qa0) and torch.equal(qb[1:2], qa1)
 
 
+def test_4k_input_frame_large_offsets():
+    """A 2160x3840 input (-> 4320x7680, 99.5 MB int8 / 398 MB fp32 out; 133 MB per NHWC16 tensor): the largest frame class the
+    32-bit buffer offsets are specified for.  Every launch plan gives the same bytes, fp32 and int8 outputs agree, and crops
+    at the four corners and the centre (7-pixel halo, so the frame borders are the crop's own borders) match the oracle."""
+    net = O.synth_net("sesr_x2", 5, hard=True)
+    b = bundle_from_oracle(net)
+    H, W = 2160, 3840
+    x = torch.rand((1, 3, H, W), generator=torch.Generator().manual_seed(9)).to(_dev())
+    e = sesrq.Engine(b, _dev())
+    q, y = e.forward(x)
+    for fh in (0, 2):
+        q2, _ = sesrq.Engine(b, _dev(), fuse_hidden=fh).forward(x, want_f=False)
+        assert torch.equal(q, q2), fh
+    zL, sL = net.zero[net.L], np.float32(net.scale[net.L])
+    assert torch.equal(y, (q.float() - zL) * float(sL))
+    for (y0, x0) in [(0, 0), (0, W - 160), (H - 120, 0), (H - 120, W - 160), (1000, 1900)]:
+        ya, xa = max(y0 - 7, 0), max(x0 - 7, 0)
+        yb, xb = min(y0 + 120 + 7, H), min(x0 + 160 + 7, W)
+        crop = x[:, :, ya:yb, xa:xb].contiguous()
+        want = O.forward(net, crop.cpu().numpy())["q_out"]
+        oy, ox = y0 - ya, x0 - xa
+        _cmp(f"4K frame, window at ({y0},{x0})", q[:, :, 2 * y0:2 * (y0 + 120), 2 * x0:2 * (x0 + 160)],
+             want[:, :, 2 * oy:2 * (oy + 120), 2 * ox:2 * (ox + 160)])
+    del q, y, q2, x
+    torch.cuda.empty_cache()
+
+
 def test_error_conventions():
     net = O.synth_net("nrdm", 0)
     b = bundle_from_oracle(net)
