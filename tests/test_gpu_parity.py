@@ -203,6 +203,12 @@ def test_4k_input_frame_large_offsets():
              want[:, :, 2 * oy:2 * (oy + 120), 2 * ox:2 * (ox + 160)])
     del q, y, q2, x
     torch.cuda.empty_cache()
+    # one step further: H*W = 2^24 pixels is refused before anything is launched (32-bit buffer offsets), not computed wrongly
+    big = torch.zeros((1, 3, 4096, 4096), device=_dev())
+    with pytest.raises(RuntimeError, match="too large for 32-bit buffer offsets"):
+        e.forward(big, want_f=False)
+    del big
+    torch.cuda.empty_cache()
 
 
 def test_error_conventions():
