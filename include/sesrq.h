@@ -183,6 +183,11 @@ int sesrq_calib_conv(const sesrq_calib_conv_desc *d, const float *in, const floa
                      int N, int H, int W, void *stream);
 /* min and max of a device fp32 tensor -> out_min_max[0..1] (device); scratch8: 8 bytes of device scratch */
 int sesrq_calib_minmax(const float *x, size_t n, float *out_min_max, void *scratch8, void *stream);
+/* Entropy (KL) calibration variant -- no reference counterpart: the reference's test.py keeps min/max only; BASELINE's north
+ * star asks for KL-entropy activation ranges.  Adds the histogram of a device fp32 tensor over [lo, hi) in `bins` (2..4096)
+ * equal bins to hist[bins] (device, uint32; the caller zeroes it): bin = floor((x - lo) * f32(bins / (hi - lo))) clamped to
+ * [0, bins-1], NaNs skipped.  The range search over the histogram is host code (sesrq/calibrate.py: entropy_range). */
+int sesrq_calib_histogram(const float *x, size_t n, float lo, float hi, int bins, uint32_t *hist, void *stream);
 /* (clamp8(rint(x/scale + zero)) - zero) * scale  (quan_func.py:207,215) */
 int sesrq_calib_fakequant(const float *in, float *out, size_t n, float scale, int zero, void *stream);
 

@@ -100,6 +100,27 @@ __global__ void calib_fakequant_kernel(const float *in, float *out, size_t n, fl
     }
 }
 
+// Histogram of a tensor over [lo, hi) in `bins` equal bins (bin = floor((x - lo) * bins / (hi - lo)), clamped to the range: values
+// outside count in the edge bins), accumulated INTO hist.  One private copy per workgroup in LDS, merged with one atomic per
+// non-empty bin: the entropy calibration variant's second pass (no reference counterpart).
+constexpr int CALIB_MAX_BINS = 4096;
+__global__ __launch_bounds__(256) void calib_hist_kernel(const float *x, size_t n, float lo, float inv_w, int bins, unsigned *hist) {
+    __shared__ unsigned h[CALIB_MAX_BINS];
+    for (int i = threadIdx.x; i < bins; i += 256) h[i] = 0;
+    __syncthreads();
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const float v = x[i];
+        if (v == v) {                    // NaNs are not counted
+            int b = (int)floorf(__fmul_rn(__fsub_rn(v, lo), inv_w));
+            b = min(max(b, 0), bins - 1);
+            atomicAdd(&h[b], 1u);
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < bins; i += 256)
+        if (h[i]) atomicAdd(&hist[i], h[i]);
+}
+
 }  // namespace sesrq
 
 using namespace sesrq;
@@ -130,6 +151,17 @@ int sesrq_calib_conv(const sesrq_calib_conv_desc *d, const float *in, const floa
     if (d->k == 3) hipLaunchKernelGGL(calib_conv_kernel<3>, grid, dim3(256), 0, (hipStream_t)stream, a);
     else hipLaunchKernelGGL(calib_conv_kernel<5>, grid, dim3(256), 0, (hipStream_t)stream, a);
     if (hipGetLastError() != hipSuccess) { set_error("sesrq_calib_conv: launch failed"); return 1; }
+    return 0;
+}
+
+int sesrq_calib_histogram(const float *x, size_t n, float lo, float hi, int bins, uint32_t *hist, void *stream) {
+    if (!x || !hist || n == 0) { set_error("sesrq_calib_histogram: bad argument"); return 1; }
+    if (bins < 2 || bins > CALIB_MAX_BINS) { set_error("sesrq_calib_histogram: bins must be 2..4096"); return 1; }
+    if (!(hi > lo) || !std::isfinite(lo) || !std::isfinite(hi)) { set_error("sesrq_calib_histogram: need finite lo < hi"); return 1; }
+    const float inv_w = (float)bins / (hi - lo);
+    const int blocks = (int)std::min<size_t>((n + 256 * 16 - 1) / (256 * 16), 2048);
+    hipLaunchKernelGGL(calib_hist_kernel, dim3(std::max(blocks, 1)), dim3(256), 0, (hipStream_t)stream, x, n, lo, inv_w, bins, (unsigned *)hist);
+    if (hipGetLastError() != hipSuccess) { set_error("sesrq_calib_histogram: launch failed"); return 1; }
     return 0;
 }
 

