@@ -159,6 +159,16 @@ def test_calibrate_then_infer_end_to_end():
     net = O.Net(layers=[O.Layer(l.wq, l.add_const, l.M, l.n, l.relu) for l in b.layers], scale=b.scale, zero=b.zero,
                 M_res=b.M_res, n_res=b.n_res, pixel_shuffle=b.pixel_shuffle)
     np.testing.assert_array_equal(y.cpu().numpy(), O.forward(net, x)["y"])
+    # the entropy variant through the same entry (two passes over the frames): ranges inside the min/max ones, so scales
+    # not larger; the output domain keeps zero = -128 (min := 0); the bundle file it writes loads and runs
+    out = os.path.join(os.environ.get("TMPDIR", "/tmp"), "sesrq_entropy_bundle.npz")
+    s2, z2 = calib.main(["--mflag", "5", "--params", os.path.join(GOLDEN, "sesr_x4.params.npz"), "--frames", frames,
+                         "--method", "entropy", "--save-bundle", out])
+    assert len(s2) == 6 and z2[5] == -128 and all(a_ <= b_ * (1 + 1e-6) for a_, b_ in zip(s2, scale))
+    from sesrq.bundle import Bundle
+    be = Bundle.load(out)
+    assert be.L == 5 and be.zero == z2
+    os.remove(out)
 
 
 def _plain_state_dict(mflag):
