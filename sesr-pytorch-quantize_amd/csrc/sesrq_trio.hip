@@ -96,11 +96,13 @@ __global__ __launch_bounds__(256) void mfma_trio_kernel(const TrioArgs a) {
     const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, n = l & 15, g = l >> 4;
     const int n_img = blockIdx.z;
     const int x0 = blockIdx.x * TV - 2;              // frame column of computed column 0
-    // vertical runs of (almost) equal length: run c of n covers steps [c*S/n, (c+1)*S/n)
-    const int steps_total = (a.H + TH - 1) / TH;
-    const int s_begin = (int)(((long long)blockIdx.y * steps_total) / gridDim.y);
-    const int s_end = (int)(((long long)(blockIdx.y + 1) * steps_total) / gridDim.y);
-    if (s_begin >= s_end) return;
+    // vertical runs of (almost) equal length in units of HALF a step (4 rows): run c of n covers units [c*U/n, (c+1)*U/n), walked
+    // in full steps plus, for an odd count, one closing half step.  With whole steps only, a 1080p frame on a full chip had
+    // runs of 4 and 5 steps (135 steps over 32 runs per strip): the kernel lasted 5 steps for 4.2 steps of work per workgroup.
+    const int units_total = (a.H + 3) / 4;
+    const int y_begin = 4 * (int)(((long long)blockIdx.y * units_total) / gridDim.y);
+    const int y_end = 4 * (int)(((long long)(blockIdx.y + 1) * units_total) / gridDim.y);
+    if (y_begin >= y_end) return;
 
     const int c = 16 * w + n, gx = x0 + c;
     const bool col_in = (gx >= 0) & (gx < a.W);                   // inner layers: inside the frame, else pad
@@ -130,14 +132,15 @@ __global__ __launch_bounds__(256) void mfma_trio_kernel(const TrioArgs a) {
     // SIMD fill the gaps.  A hand-pipelined variant (MFMAs of the next 4 rows issued before the epilogues of the previous 4,
     // weights in LDS to stay at 4 waves per SIMD) ran 11 % SLOWER alone (42 vs 38 us at 1080p) and the same with two frames in
     // flight (same-box A/B, round 2): the instruction count is what bounds this kernel, not the order inside one wave.
-    auto inner = [&](auto KC, auto I0, const int4 *src, int4 *dst, int row0) __attribute__((always_inline)) {
-        constexpr int K = decltype(KC)::value, i0 = decltype(I0)::value;
+    // rows i0 .. i1-1 of the step: (0, 8) a full step, (4, 8) / (6, 8) the cold start, (0, 4) the half step that closes a run
+    auto inner = [&](auto KC, auto I0, auto I1, const int4 *src, int4 *dst, int row0) __attribute__((always_inline)) {
+        constexpr int K = decltype(KC)::value, i0 = decltype(I0)::value, i1 = decltype(I1)::value;
         const TrioLayer &L = a.l[K];
         const int4 *p = src + rdcol;
         unsigned *d = reinterpret_cast<unsigned *>(dst) + wrcol;
         v4i B0 = ld_frag(p + (i0)*TP), B1 = ld_frag(p + (i0 + 1) * TP);
 #pragma unroll
-        for (int i = i0; i < TH; ++i) {
+        for (int i = i0; i < i1; ++i) {
             const v4i B2 = ld_frag(p + (i + 2) * TP);
             v4i acc = mfma(A[K][0], B0, acc0[K]);
             acc = mfma(A[K][1], B1, acc);
@@ -151,13 +154,14 @@ __global__ __launch_bounds__(256) void mfma_trio_kernel(const TrioArgs a) {
             d[(2 + i) * TP * 4] = q;
         }
     };
-    // outer layer: output rows Y .. Y+7 from window positions 0 .. 9 of layer b
-    auto outer = [&](int Y) __attribute__((always_inline)) {
+    // outer layer: output rows Y .. Y+NR-1 (NR = 8, or 4 in a half step) from window positions 0 .. NR+1 of layer b
+    auto outer = [&](auto NRC, int Y) __attribute__((always_inline)) {
+        constexpr int NR = decltype(NRC)::value;
         const int4 *p = bufB + rdcol;
         io.voff = col_out ? voff_c + Y * io.row_bytes : OOB;
         v4i B0 = ld_frag(p), B1 = ld_frag(p + TP);
 #pragma unroll
-        for (int y4 = 0; y4 < TH; y4 += 4) {
+        for (int y4 = 0; y4 < NR; y4 += 4) {
             int s4[4][4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -179,30 +183,35 @@ __global__ __launch_bounds__(256) void mfma_trio_kernel(const TrioArgs a) {
 
     TrioStage st;
     st.init(a, n_img, x0, tid);
-    // ---- cold start: the step before the chunk's first one, only the rows the first real step needs
+    using IC0 = integral_constant<int, 0>;
+    using IC1 = integral_constant<int, 1>;
+    using IC4 = integral_constant<int, 4>;
+    using IC6 = integral_constant<int, 6>;
+    using IC8 = integral_constant<int, 8>;
+    // ---- cold start: the step before the run's first one, only the rows the first real step needs
     {
-        const int Y = (s_begin - 1) * TH;
+        const int Y = y_begin - TH;
         st.load<true>(a, Y + 1);
         st.store<true>(bufI, a.pad_in, tid);
         __syncthreads();
         st.load<false>(a, Y + TH + 3);
-        inner(integral_constant<int, 0>(), integral_constant<int, 4>(), bufI, bufA, Y + 2);
+        inner(IC0(), IC4(), IC8(), bufI, bufA, Y + 2);
         int4 shI = make_int4(0, 0, 0, 0);
         if (tid < 2 * TP) shI = bufI[TH * TP + tid];
         __syncthreads();
         if (tid < 2 * TP) bufI[tid] = shI;
         st.store<false>(bufI, a.pad_in, tid);
-        inner(integral_constant<int, 1>(), integral_constant<int, 6>(), bufA, bufB, Y + 1);
+        inner(IC1(), IC6(), IC8(), bufA, bufB, Y + 1);
         __syncthreads();
         shift(bufA);
         __syncthreads();
     }
-    for (int s = s_begin; s < s_end; ++s) {
-        const int Y = s * TH;
-        const bool more = s + 1 < s_end;
-        if (more) st.load<false>(a, Y + TH + 3);                 // next step's new input rows, consumed after the first barrier
+    int Y = y_begin;
+    for (; y_end - Y >= TH; Y += TH) {
+        const bool more = Y + TH < y_end;                        // another step (full or half) follows
+        if (more) st.load<false>(a, Y + TH + 3);                 // its new input rows, consumed after the first barrier
         shift(bufB);                                             // layer-b rows Y-1, Y (phase c of the previous step is done)
-        inner(integral_constant<int, 0>(), integral_constant<int, 0>(), bufI, bufA, Y + 2);
+        inner(IC0(), IC0(), IC8(), bufI, bufA, Y + 2);
         int4 shI = make_int4(0, 0, 0, 0);
         if (tid < 2 * TP) shI = bufI[TH * TP + tid];
         __syncthreads();
@@ -210,11 +219,19 @@ __global__ __launch_bounds__(256) void mfma_trio_kernel(const TrioArgs a) {
             if (tid < 2 * TP) bufI[tid] = shI;
             st.store<false>(bufI, a.pad_in, tid);
         }
-        inner(integral_constant<int, 1>(), integral_constant<int, 0>(), bufA, bufB, Y + 1);
+        inner(IC1(), IC0(), IC8(), bufA, bufB, Y + 1);
         __syncthreads();
         shift(bufA);
-        outer(Y);
+        outer(IC8(), Y);
         __syncthreads();
+    }
+    if (Y < y_end) {                                             // the closing half step: output rows Y .. Y+3
+        shift(bufB);
+        inner(IC0(), IC0(), IC4(), bufI, bufA, Y + 2);
+        __syncthreads();
+        inner(IC1(), IC0(), IC4(), bufA, bufB, Y + 1);
+        __syncthreads();
+        outer(IC4(), Y);
     }
 }
 
@@ -240,10 +257,10 @@ static void launch_trio_k(K kern, TrioArgs a, hipStream_t st) {
         }
     }
     const int lds = std::max(TRIO_LDS_BYTES, (160 * 1024 / occ) & ~1023);      // exactly occ workgroups per 160 KiB
-    const int strips = (a.W + TV - 1) / TV, steps = (a.H + TH - 1) / TH;
+    const int strips = (a.W + TV - 1) / TV, units = (a.H + 3) / 4;       // a run is at least one half step (4 rows)
     long long k = (a.wg_budget > 0 ? (long long)a.wg_budget : (long long)occ * num_cu) / ((long long)strips * a.N);
-    k = std::max(1LL, std::min<long long>(k, steps));
-    a.chunk_steps = (int)((steps + k - 1) / k);
+    k = std::max(1LL, std::min<long long>(k, (units + 1) / 2));           // ... and on average at least one full step
+    a.chunk_steps = (int)((units + k - 1) / k);
     dim3 grid(strips, (int)k, a.N);
     launch_kernel(kern, grid, dim3(256), (unsigned)lds, st, a);
 }
