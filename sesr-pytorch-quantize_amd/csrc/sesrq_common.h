@@ -86,7 +86,8 @@ struct TrioArgs {
     void *out;               // NHWC16 output of the third layer
     const void *rc_in;       // EPI_PRERES: residual operand tensor
     int N, H, W;
-    int chunk_steps;         // trio: 4-row units (half steps) per run, rounded up; fused front: 8-row steps per run
+    int chunk_steps;         // 8-row steps per run, rounded up
+    int run_unit;            // trio: rows per partition unit of the vertical runs, 8 (whole steps) or 4 (half steps)
     int wg_budget;           // workgroup slots the launch may fill (0 = one round of the chip)
     int pad_in;              // pad word of the first layer's input
     float Mres, shres, z_merge;

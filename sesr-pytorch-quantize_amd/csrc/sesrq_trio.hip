@@ -96,12 +96,14 @@ __global__ __launch_bounds__(256) void mfma_trio_kernel(const TrioArgs a) {
     const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, n = l & 15, g = l >> 4;
     const int n_img = blockIdx.z;
     const int x0 = blockIdx.x * TV - 2;              // frame column of computed column 0
-    // vertical runs of (almost) equal length in units of HALF a step (4 rows): run c of n covers units [c*U/n, (c+1)*U/n), walked
-    // in full steps plus, for an odd count, one closing half step.  With whole steps only, a 1080p frame on a full chip had
-    // runs of 4 and 5 steps (135 steps over 32 runs per strip): the kernel lasted 5 steps for 4.2 steps of work per workgroup.
-    const int units_total = (a.H + 3) / 4;
-    const int y_begin = 4 * (int)(((long long)blockIdx.y * units_total) / gridDim.y);
-    const int y_end = 4 * (int)(((long long)(blockIdx.y + 1) * units_total) / gridDim.y);
+    // vertical runs of (almost) equal length: run c of n covers units [c*U/n, (c+1)*U/n) of a.run_unit rows -- whole steps (8), or
+    // half steps (4) where the runs are short (the launch decides): such a run is walked in full steps plus, for an odd count,
+    // one closing half step.  A 540p frame on a full chip has 1 - 2 steps per run: 8- and 16-row runs became 8- and 12-row
+    // runs, 18.8 -> 14.8 us.  Long runs (1080p: 4 - 5 steps) gain nothing from it -- the workgroups that finish early leave
+    // their issue slots to the others -- and a half step costs more than half a step, so they stay on whole steps.
+    const int units_total = (a.H + a.run_unit - 1) / a.run_unit;
+    const int y_begin = a.run_unit * (int)(((long long)blockIdx.y * units_total) / gridDim.y);
+    const int y_end = a.run_unit * (int)(((long long)(blockIdx.y + 1) * units_total) / gridDim.y);
     if (y_begin >= y_end) return;
 
     const int c = 16 * w + n, gx = x0 + c;
@@ -257,10 +259,12 @@ static void launch_trio_k(K kern, TrioArgs a, hipStream_t st) {
         }
     }
     const int lds = std::max(TRIO_LDS_BYTES, (160 * 1024 / occ) & ~1023);      // exactly occ workgroups per 160 KiB
-    const int strips = (a.W + TV - 1) / TV, units = (a.H + 3) / 4;       // a run is at least one half step (4 rows)
+    const int strips = (a.W + TV - 1) / TV, steps = (a.H + TH - 1) / TH;
     long long k = (a.wg_budget > 0 ? (long long)a.wg_budget : (long long)occ * num_cu) / ((long long)strips * a.N);
-    k = std::max(1LL, std::min<long long>(k, (units + 1) / 2));           // ... and on average at least one full step
-    a.chunk_steps = (int)((units + k - 1) / k);
+    k = std::max(1LL, std::min<long long>(k, steps));                     // a run is at least one full step on average
+    a.chunk_steps = (int)((steps + k - 1) / k);
+    a.run_unit = (steps < 3 * k) ? TH / 2 : TH;                           // short runs (< 3 steps) are cut in half-step units
+    if (const char *e = getenv("SESRQ_TRIO_UNIT")) { if (atoi(e) == 4 || atoi(e) == 8) a.run_unit = atoi(e); }     // tuning knob
     dim3 grid(strips, (int)k, a.N);
     launch_kernel(kern, grid, dim3(256), (unsigned)lds, st, a);
 }
