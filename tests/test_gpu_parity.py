@@ -129,6 +129,29 @@ def test_general_and_merged_kernels_agree(eng):
     _cmp("q_out", q0, want["q_out"])
 
 
+@pytest.mark.parametrize("cin", [2, 4])
+def test_first_layer_with_two_and_four_input_channels(cin):
+    """The first-layer kernels are specialised for 1 and 3 input channels (the reference's nets); any other count up to the
+    PE width (a 4-channel Bayer RGGB frame, say) takes the run-time channel path of the same kernels: fp32 and int8 frames,
+    every launch plan, merged and per-PE accumulation."""
+    rng = np.random.default_rng(70 + cin)
+    for hard in (False, True):
+        net = O.synth_net("nrdm", 30 + cin, hard=hard)
+        w0 = net.layers[0].wq
+        net.layers[0].wq = rng.integers(-128, 128, size=(w0.shape[0], cin, 5, 5)).astype(np.int8) if hard else \
+            np.clip(np.rint(rng.standard_normal((w0.shape[0], cin, 5, 5)) * 14.0), -128, 127).astype(np.int8)
+        x = rng.random((2, cin, 37, 91), dtype=np.float32)
+        want = O.forward(net, x)
+        q0 = O.quantize_input(x, net.scale[0], net.zero[0])
+        for name, kw in ENGINES:
+            e = make_engine(net, (name, kw))
+            q, y = e.forward(torch.from_numpy(x).to(_dev()))
+            _cmp(f"cin {cin} hard {hard} {name} {e.layer_engines()[0]}", q, want["q_out"])
+            _cmp("y", y, want["y"])
+            q8, _ = e.forward(torch.from_numpy(q0).to(_dev()), want_f=False)
+            _cmp(f"cin {cin} hard {hard} {name}: int8 frame", q8, want["q_out"])
+
+
 def test_int8_input_path():
     """The boundary also accepts an already-quantised q0 (input.0.pt) instead of the fp32 frame."""
     net = O.synth_net("nrdm", 2, hard=True)
