@@ -152,6 +152,27 @@ def test_first_layer_with_two_and_four_input_channels(cin):
             _cmp(f"cin {cin} hard {hard} {name}: int8 frame", q8, want["q_out"])
 
 
+@pytest.mark.parametrize("acc_bits,add_bits", [(16, 18), (17, 17), (20, 22), (24, 26)])
+def test_other_pe_bit_widths(acc_bits, add_bits):
+    """define.py's PE_ACC_BIT / PE_ADD_BIT are configuration, not constants: narrower accumulators saturate often (and with
+    add_bits <= acc_bits + 1 the adder clamp is no longer a provable no-op), wider ones never -- the kernels take the widths
+    from the bundle (literal clamps only for the reference's 18 / 20).  Every engine vs the oracle, C oracle vs numpy."""
+    from oracle import c_oracle as CO
+    for kind in ("sesr_x2", "nrdm"):
+        net = O.synth_net(kind, 11, hard=True)
+        net.acc_bits, net.add_bits = acc_bits, add_bits
+        x = rand_frame((1, 3, 30, 77), 5)
+        want = O.forward(net, x, keep=True)
+        sat = [int((np.abs(want[f"pe_raw{k}"]) >= 2 ** (acc_bits - 1)).sum()) for k in range(net.L)]
+        assert (sum(sat) > 0) == (acc_bits < 20), sat                   # the narrow cases really saturate, the wide ones never
+        _cmp("C oracle vs numpy oracle", CO.forward(net, x)["q_out"], want["q_out"])
+        for name, kw in ENGINES:
+            e = make_engine(net, (name, kw))
+            q, y = e.forward(torch.from_numpy(x).to(_dev()))
+            _cmp(f"{kind} acc {acc_bits} add {add_bits} {name} {e.layer_engines()}", q, want["q_out"])
+            _cmp("y", y, want["y"])
+
+
 def test_int8_input_path():
     """The boundary also accepts an already-quantised q0 (input.0.pt) instead of the fp32 frame."""
     net = O.synth_net("nrdm", 2, hard=True)
