@@ -86,7 +86,9 @@ static bool saturation_free(const sesrq_layer_desc &d, int zc, int acc_bits, int
 // the same (g, b) slot -- the tables below are the single source of truth for both sides
 // (kernels: sesrq_mfma.hip).
 // zero_pe >= 0: the channels of that PE carry no weights (hybrid kernels: the chain of the other three PEs)
-static void pack_mfma_frags(const sesrq_layer_desc &d, int kind, bool general, bool last, std::vector<int> &out, int zero_pe = -1) {
+// lastnv: 0 = hidden / first layer (PE-major channel order); 3 / 4 = last layer with that many real rows per lane group
+// (last_slot_oc, sesrq_common.h), ps = its PixelShuffle factor
+static void pack_mfma_frags(const sesrq_layer_desc &d, int kind, bool general, int lastnv, int ps, std::vector<int> &out, int zero_pe = -1) {
     const int taps = d.k * d.k;
     int F = 0;
     switch (kind) {
@@ -98,7 +100,7 @@ static void pack_mfma_frags(const sesrq_layer_desc &d, int kind, bool general, b
     out.assign((size_t)16 + (size_t)F * 64 * 4, 0);
     // MFMA_H5P (last layer, OC <= 4): accumulator row m = (PE m/4, output channel m%4); a row only carries
     // the weights of its PE's channels, so one chain over the full K yields the four per-PE sums
-    auto ocmap = [&](int m) { return kind == MFMA_H5P ? (m & 3) : (last ? m : (m >> 2) + 4 * (m & 3)); };
+    auto ocmap = [&](int m) { return kind == MFMA_H5P ? (m & 3) : (lastnv ? last_slot_oc(lastnv, m >> 2, m & 3, d.oc, ps) : (m >> 2) + 4 * (m & 3)); };
     for (int m = 0; m < 16; ++m) out[m] = (ocmap(m) < d.oc && !(kind == MFMA_H5P && m > 3)) ? d.add_const[ocmap(m)] : 0;
     auto chmap16 = [](int b) { return (b >> 2) + 4 * (b & 3); };
     signed char *bytes = reinterpret_cast<signed char *>(out.data() + 16);
@@ -117,21 +119,10 @@ static void pack_mfma_frags(const sesrq_layer_desc &d, int kind, bool general, b
                     else if (f == 5) { ky = g; kx = 4; }
                     else if (g == 0) { ky = 4; kx = 4; }
                 } else if (kind == MFMA_H5) {
-                    // per PE p two K-chunks: 0: lane group g = one kernel row, words = kx 0..3;  1: row 4 + column 4 by four
-                    // translates of the pixel pattern {(0,0),(1,0),(2,0),(2,2)} (same scheme as MFMA_F5)
-                    // lane groups of a 32-lane half are two image rows apart (bank-conflict-free LDS reads, sesrq_mfma.hip):
-                    // chunk 0: groups (0,1,2,3) = kernel rows (0,2,1,3); chunk 1: translations (0,4) (2,4) (2,0) (2,1)
+                    // per PE p two K-chunks of two vertical pixel pairs per lane group: dword i = pair i / 2, element i % 2 (h5_tap)
                     const int fi = f >> 2, p = f & 3;
-                    static const int kyg[4] = {0, 2, 1, 3};
-                    static const int tr[4][2] = {{0, 4}, {2, 4}, {2, 0}, {2, 1}};
-                    static const int pt[4][2] = {{0, 0}, {1, 0}, {2, 0}, {2, 2}};
                     ch = p + 4 * j;
-                    if (fi == 0) { ky = kyg[g]; kx = i; }
-                    else {
-                        ky = tr[g][0] + pt[i][0]; kx = tr[g][1] + pt[i][1];
-                        const bool in_l = (ky == 4 && kx <= 4) || (kx == 4 && ky <= 4);
-                        if (!in_l || (g == 1 && i == 0)) ky = -1;          // tap (2,4) belongs to lane group 0
-                    }
+                    if (!h5_tap(fi, g, i >> 1, i & 1, ky, kx)) ky = -1;
                 }
                 else if (kind == MFMA_H5P) {
                     ch = chmap16(b);
@@ -291,9 +282,10 @@ int sesrq_create(const sesrq_net_desc *d, const sesrq_options *opts, sesrq_net *
         else if (l.k == 3 && k < L - 1) lp.mfma_kind = MFMA_H3;
         else if (l.k == 5) lp.mfma_kind = MFMA_H5;
         if (lp.mfma_kind != MFMA_NONE) {
+            const int lastnv = (k == L - 1) ? last_nv(l.oc) : 0;
             for (int gen = 0; gen < 2; ++gen) {
                 std::vector<int> fr;
-                pack_mfma_frags(l, lp.mfma_kind, gen == 1, k == L - 1, fr);
+                pack_mfma_frags(l, lp.mfma_kind, gen == 1, lastnv, d->pixel_shuffle, fr);
                 int4 **dst = gen ? &lp.d_afrag_general : &lp.d_afrag_merged;
                 if (hipMalloc((void **)dst, fr.size() * sizeof(int)) != hipSuccess ||
                     hipMemcpy(*dst, fr.data(), fr.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess) {
@@ -304,7 +296,7 @@ int sesrq_create(const sesrq_net_desc *d, const sesrq_options *opts, sesrq_net *
             }
             if (lp.general && __builtin_popcount(lp.risky_mask) == 1) {      // hybrid kernels: merged chain without the risky PE
                 std::vector<int> fr;
-                pack_mfma_frags(l, lp.mfma_kind, false, k == L - 1, fr, __builtin_ctz(lp.risky_mask));
+                pack_mfma_frags(l, lp.mfma_kind, false, lastnv, d->pixel_shuffle, fr, __builtin_ctz(lp.risky_mask));
                 if (hipMalloc((void **)&lp.d_afrag_others, fr.size() * sizeof(int)) != hipSuccess ||
                     hipMemcpy(lp.d_afrag_others, fr.data(), fr.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess) {
                     set_error("sesrq_create: device upload failed");
@@ -314,7 +306,7 @@ int sesrq_create(const sesrq_net_desc *d, const sesrq_options *opts, sesrq_net *
             }
             if (k == L - 1 && lp.mfma_kind == MFMA_H5 && l.oc <= 4) {
                 std::vector<int> fr;
-                pack_mfma_frags(l, MFMA_H5P, true, true, fr);
+                pack_mfma_frags(l, MFMA_H5P, true, 4, d->pixel_shuffle, fr);
                 if (hipMalloc((void **)&lp.d_afrag_pesplit, fr.size() * sizeof(int)) != hipSuccess ||
                     hipMemcpy(lp.d_afrag_pesplit, fr.data(), fr.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess) {
                     set_error("sesrq_create: device upload failed");

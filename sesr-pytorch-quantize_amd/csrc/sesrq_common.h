@@ -22,6 +22,54 @@ inline void launch_kernel(K kern, dim3 grid, dim3 block, unsigned lds, hipStream
 }
 
 enum Epi { EPI_MID = 0, EPI_PRERES = 1, EPI_LAST = 2 };
+
+// 5x5 per-PE chains (MFMA_H5 general image; kernels: mfma_h5_kernel).  A lane's 16 operand bytes per PE and K-chunk are TWO
+// VERTICAL PAIRS of pixels: K-chunk c, lane group g, pair q covers the taps (ky = start, start + 1; kx = col) of
+// h5_pair(c, g, q).  In the column-major planar LDS image (sesrq_mfma.hip) a vertical pair is two adjacent dwords = one
+// ds_read2_b32 into two consecutive registers, and the two lane groups of a 32-lane half (the conflict domain of a dword read)
+// always sit an ODD number of rows apart, which with a column pitch of 2 mod 4 dwords puts them on disjoint banks.  15 pairs
+// cover the 25 taps (every column: start 0, start 3, and start 1 or 2); a tap covered twice carries its weight in the FIRST
+// pair of the order (c, q, g) only (h5_tap), the 16th pair is padding.
+__host__ __device__ inline void h5_pair(int c, int g, int q, int &col, int &start) {
+    //                         g0      g1      g2      g3
+    const int tab[4][4][2] = {{{0, 0}, {0, 3}, {1, 0}, {1, 3}},      // chunk 0, pair 0
+                              {{2, 0}, {2, 3}, {3, 0}, {3, 3}},      // chunk 0, pair 1
+                              {{4, 0}, {4, 3}, {0, 2}, {1, 1}},      // chunk 1, pair 0
+                              {{2, 2}, {3, 1}, {4, 2}, {4, 1}}};     // chunk 1, pair 1  (g3: padding)
+    col = tab[c * 2 + q][g][0];
+    start = tab[c * 2 + q][g][1];
+}
+// tap of element e (0, 1) of that pair, or false if the tap already belongs to an earlier pair / the pair is padding
+__host__ __device__ inline bool h5_tap(int c, int g, int q, int e, int &ky, int &kx) {
+    int col, start;
+    h5_pair(c, g, q, col, start);
+    ky = start + e; kx = col;
+    for (int cc = 0; cc < 2; ++cc)
+        for (int qq = 0; qq < 2; ++qq)
+            for (int gg = 0; gg < 4; ++gg) {
+                if (cc == c && qq == q && gg == g) return !(c == 1 && q == 1 && g == 3);
+                int c2, s2;
+                h5_pair(cc, gg, qq, c2, s2);
+                if (c2 == col && (s2 == ky || s2 + 1 == ky)) return false;
+            }
+    return false;
+}
+
+// Last layer on the MFMA engine (mfma_h5_kernel<.., EPI_LAST>): which output channel sits in accumulator row 4g + i, i.e. in
+// register i of lane group g.  With 16 rows in channel order a 12-channel layer (SESR-x2: 3 colours x PixelShuffle(2)) leaves
+// lane group 3 -- a quarter of every clamp / requant / store instruction -- working on padding.  nv = 3 puts the padding into
+// REGISTER 3 of every lane instead (rows 4g + 3 carry no weights and are never looked at): all 64 lanes own three real
+// channels.  For PixelShuffle(2) x 12 channels the three are a 2-byte run (channels 2g, 2g+1 = two horizontally adjacent
+// sub-pixels) and one single (channel 8 + g): one 2-byte and one 1-byte store per lane and row.
+// Single source of truth for pack_mfma_frags (host) and LastStore (device).
+__host__ __device__ inline int last_nv(int oc) { return oc <= 12 ? 3 : 4; }
+__host__ __device__ inline bool last_pairmap(int oc, int ps) { return oc == 12 && ps == 2; }
+__host__ __device__ inline int last_slot_oc(int nv, int g, int i, int oc, int ps) {
+    if (nv == 4) return 4 * g + i;
+    if (i == 3) return 255;                                 // padding row
+    if (last_pairmap(oc, ps)) return i < 2 ? 2 * g + i : 8 + g;
+    return 3 * g + i;
+}
 enum Src { SRC_NHWC16 = 0, SRC_F32 = 1, SRC_I8 = 2, SRC_I8D = 3 };   // I8D: int8 frame in an upstream net's output domain
 enum MfmaKind { MFMA_NONE = 0, MFMA_H3 = 1, MFMA_H5 = 2, MFMA_F5 = 3, MFMA_H5P = 4 };
 

@@ -55,7 +55,8 @@ struct LastStore {
     const float *anc;
     int r, row_elems;     // PixelShuffle factor, r * Wo
     // lane_row: the lane's output row relative to the row passed to store() (pe-split kernel: lane group = row)
-    template <int R>
+    // NV: real accumulator rows per lane group (last_slot_oc, sesrq_common.h); slot i >= NV of a lane is padding
+    template <int R, int NV>
     __device__ __forceinline__ void init_r(const ConvArgs &a, int n_img, int g, int gx, int lane_row) {
         r = R;
         constexpr int r2 = R * R;
@@ -63,10 +64,10 @@ struct LastStore {
         const size_t img = (size_t)cout * Ho * Wo;
         rq = __builtin_amdgcn_make_buffer_rsrc((char *)a.out_q + (size_t)n_img * img, 0, a.out_q ? (int)img : 0, 0x00020000);
         rf = __builtin_amdgcn_make_buffer_rsrc((char *)a.out_f + (size_t)n_img * img * 4, 0, a.out_f ? (int)(img * 4) : 0, 0x00020000);
-        row_elems = R * Wo;
+        row_elems = __builtin_amdgcn_readfirstlane(R * Wo);      // pinned to an SGPR: the row's store offset is then scalar arithmetic
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int o = 4 * g + i;
+            const int o = last_slot_oc(NV, g, i, a.oc, R);
             const int c = o / r2, rem = o - c * r2, ii = rem / R, jj = rem - ii * R;
             vo[i] = (o < a.oc && gx < a.W) ? (c * Ho + ii + lane_row * R) * Wo + gx * R + jj : (int)0x10000000;   // stays out of range times 4
             va[i] = (o < a.oc && gx < a.W) ? c * a.H * a.W + gx + lane_row * a.W : 0;
@@ -74,31 +75,48 @@ struct LastStore {
         anc = a.anchor ? a.anchor + (size_t)n_img * cout * a.H * a.W : nullptr;
     }
     // the shuffle factor is a constant in each branch: the slot decode costs shifts, not integer divisions
+    template <int NV = 4>
     __device__ __forceinline__ void init(const ConvArgs &a, int n_img, int g, int gx, int lane_row = 0) {
         switch (a.ps) {
-            case 1: init_r<1>(a, n_img, g, gx, lane_row); break;
-            case 2: init_r<2>(a, n_img, g, gx, lane_row); break;
-            case 3: init_r<3>(a, n_img, g, gx, lane_row); break;
-            default: init_r<4>(a, n_img, g, gx, lane_row); break;
+            case 1: init_r<1, NV>(a, n_img, g, gx, lane_row); break;
+            case 2: init_r<2, NV>(a, n_img, g, gx, lane_row); break;
+            case 3: init_r<3, NV>(a, n_img, g, gx, lane_row); break;
+            default: init_r<4, NV>(a, n_img, g, gx, lane_row); break;
         }
     }
     // gy: wave-uniform row; row_ok: false drops this lane's stores (lanes whose own row gy + lane_row is below the frame)
     // FAST = 2 / 4: PixelShuffle factor known at compile time, int8 output only, row_ok wave-uniform: no output-kind /
     // shuffle-factor / row branches and no per-row offset selects in the hot loop of the SESR last layer
-    template <bool BIASED, int FAST = 0>
+    // NV = 3: the lane's three real values are s[0..2] (s[3] is the padding row: never read).  FAST = 2 with NV = 3 is the
+    // pair map of last_slot_oc (12 channels, PixelShuffle(2)): bytes 0, 1 = one 2-byte run, byte 2 = a single.
+    template <bool BIASED, int FAST = 0, int NV = 4>
     __device__ __forceinline__ void store(const int s[4], const ConvArgs &a, int gy, float zlo, bool row_ok = true) const {
         v2f v01, v23;
-        requant4<BIASED>(s, a.Mf, a.sh, a.z_out, v01, v23);
+        if constexpr (NV == 4) {
+            requant4<BIASED>(s, a.Mf, a.sh, a.z_out, v01, v23);
+        } else {
+            const int s3[4] = {s[0], s[1], s[2], s[2]};
+            requant4<BIASED>(s3, a.Mf, a.sh, a.z_out, v01, v23);
+        }
         const v2f mg = {MAGIC, MAGIC};
-        v2f c01 = {med3(v01[0], zlo, 127.f), med3(v01[1], zlo, 127.f)}, c23 = {med3(v23[0], zlo, 127.f), med3(v23[1], zlo, 127.f)};
-        c01 = c01 + mg; c23 = c23 + mg;                    // low mantissa bits = rint(value), two's complement
+        v2f c01 = {med3(v01[0], zlo, 127.f), med3(v01[1], zlo, 127.f)}, c23 = {med3(v23[0], zlo, 127.f), NV == 4 ? med3(v23[1], zlo, 127.f) : 0.f};
+        c01 = c01 + mg;                    // low mantissa bits = rint(value), two's complement
+        if constexpr (NV == 4) c23 = c23 + mg; else c23[0] = c23[0] + MAGIC;
         // scalar offset of the row: gy is wave-uniform by contract, but derives from threadIdx (the wave index), so the
         // compiler must be TOLD -- the GEN_STD last layer otherwise wraps every store in a waterfall loop (readfirstlane /
         // compare / saveexec / branch), which also keeps a row's stores from overlapping the next row's MFMA chain
         // FAST: row_ok is wave-uniform too (the whole row is inside the frame or not); a row outside gets an offset the
         // buffer's range check rejects (it adds voffset + soffset in wide arithmetic, tools/oob_probe.hip)
-        const int so = __builtin_amdgcn_readfirstlane((FAST == 0 || row_ok) ? gy * row_elems : 0x7fff0000);
-        if constexpr (FAST != 0) {
+        // FAST: the row pitch is rebuilt from the kernel argument (row_elems went through the switch of init() and came back
+        // in a VGPR: v_mul_lo + v_cndmask + v_readfirstlane per row instead of two scalar instructions)
+        const int so = __builtin_amdgcn_readfirstlane((FAST == 0 || row_ok) ? gy * (FAST != 0 ? FAST * FAST * a.W : row_elems) : 0x7fff0000);
+        if constexpr (FAST != 0 && NV == 3) {
+            static_assert(FAST == 2, "three real rows per lane group: the PixelShuffle(2) pair map only");
+            const unsigned w01 = __builtin_amdgcn_perm(fbits(c01[1]), fbits(c01[0]), 0x0c0c0400u);
+            __builtin_amdgcn_raw_buffer_store_b16((unsigned short)w01, rq, this->vo[0], so, 0);
+            __builtin_amdgcn_raw_buffer_store_b8((unsigned char)fbits(c23[0]), rq, this->vo[2], so, 0);
+            return;
+        } else if constexpr (FAST != 0) {
             const unsigned w = pack_lo_bytes(fbits(c01[0]), fbits(c01[1]), fbits(c23[0]), fbits(c23[1]));
             if constexpr (FAST == 2) {
                 __builtin_amdgcn_raw_buffer_store_b16((unsigned short)(w & 0xffffu), rq, this->vo[0], so, 0);
@@ -113,21 +131,24 @@ struct LastStore {
         for (int i = 0; i < 4; ++i) vo[i] = row_ok ? this->vo[i] : (int)0x10000000;
         if (a.out_q) {
             const unsigned w = pack_lo_bytes(fbits(c01[0]), fbits(c01[1]), fbits(c23[0]), fbits(c23[1]));
-            if (r == 2) {
+            if (NV == 4 && r == 2) {
                 __builtin_amdgcn_raw_buffer_store_b16((unsigned short)(w & 0xffffu), rq, vo[0], so, 0);
                 __builtin_amdgcn_raw_buffer_store_b16((unsigned short)(w >> 16), rq, vo[2], so, 0);
-            } else if (r == 4) {
+            } else if (NV == 4 && r == 4) {
                 __builtin_amdgcn_raw_buffer_store_b32(w, rq, vo[0], so, 0);
+            } else if (NV == 3 && last_pairmap(a.oc, r)) {
+                __builtin_amdgcn_raw_buffer_store_b16((unsigned short)(w & 0xffffu), rq, vo[0], so, 0);
+                __builtin_amdgcn_raw_buffer_store_b8((unsigned char)((w >> 16) & 0xffu), rq, vo[2], so, 0);
             } else {
 #pragma unroll
-                for (int i = 0; i < 4; ++i) __builtin_amdgcn_raw_buffer_store_b8((unsigned char)((w >> (8 * i)) & 0xffu), rq, vo[i], so, 0);
+                for (int i = 0; i < NV; ++i) __builtin_amdgcn_raw_buffer_store_b8((unsigned char)((w >> (8 * i)) & 0xffu), rq, vo[i], so, 0);
             }
         }
         if (a.out_f) {
             const v2f q01 = c01 - mg, q23 = c23 - mg;      // exact: back to the integer-valued float
             const float q[4] = {q01[0], q01[1], q23[0], q23[1]};
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
+            for (int i = 0; i < NV; ++i) {
                 float yv = __fmul_rn(q[i] - a.z_out, a.s_out);
                 if (anc && row_ok) yv = __fadd_rn(yv, anc[va[i] + gy * a.W]);   // + nearest-upsampled input (test.py:148-155)
                 __builtin_amdgcn_raw_buffer_store_b32(fbits(yv), rf, vo[i] * 4, so * 4, 0);
@@ -144,7 +165,10 @@ struct LastStore {
 //   PW  > 0: PE-planar image for the per-PE (general) kernels: row pitch 4*PW dwords, dword [row][p][col] = word p
 //            (the 4 channels of PE p) of the pixel -- a lane's MFMA operand (4 pixels of ONE PE) is then read
 //            directly by dword loads with immediate plane offsets, no register shuffling.
-template <int SH, int SW, int R, int PW = 0>
+//   CP  > 0: column-major PE-planar image (5x5 per-PE kernel): dword [col][p][row], plane pitch CP >= SH, column pitch 4*CP + 2
+//            -- vertical neighbours are 1 dword apart, horizontal ones 4*CP + 2, the four planes CP: every operand dword of every
+//            row of a tile is within the 8-bit dword offsets of ds_read2_b32 from ONE lane-constant address.
+template <int SH, int SW, int R, int PW = 0, int CP = 0>
 struct StageNHWC16 {
     static constexpr int NIT = (SH * SW + 255) / 256;
     v4u v[NIT];
@@ -195,7 +219,14 @@ struct StageNHWC16 {
             const int i = tid + it * 256;
             const v4u pad = {pw, pw, pw, pw};
             const v4u t = ok[it] ? v[it] : pad;
-            if constexpr (PW == 0) {
+            if constexpr (CP > 0) {
+                int *tw = reinterpret_cast<int *>(tile);
+                const int row = i / SW, col = i - row * SW;
+                if (i < SH * SW) {
+                    int *d = tw + col * (4 * CP + 2) + row;
+                    d[0] = (int)t[0]; d[CP] = (int)t[1]; d[2 * CP] = (int)t[2]; d[3 * CP] = (int)t[3];
+                }
+            } else if constexpr (PW == 0) {
                 if (i < SH * SW) tile[i] = make_int4((int)t[0], (int)t[1], (int)t[2], (int)t[3]);
             } else {
                 int *tw = reinterpret_cast<int *>(tile);
@@ -330,20 +361,29 @@ __global__ __launch_bounds__(256) void mfma_h3_kernel(const ConvArgs a) {
 
 // ------------------------------------------------------------------ 5x5, 16 input channels
 // FAST (EPI_LAST only): 2 / 4 = PixelShuffle factor, int8 output only (LastStore::store); 0 = every output kind
-template <int MODE, int EPI, int FAST = 0>
-__global__ __launch_bounds__(256) void mfma_h5_kernel(const ConvArgs a) {
+// Waves per SIMD the register allocation is held to (A/B knob).  Round 3, same-box A/B at 1080p: 5 waves (96 VGPRs, a handful of
+// spills outside the row loop, a fifth workgroup per CU) ran the last layer 5 % SLOWER than 4 (29.3 vs 27.7 us) and the fused trio
+// 13 % slower (47.1 vs 41.6 us): the SIMDs' instruction issue is already ~80-90 % occupied by four waves.
+#ifndef SESRQ_H5_WAVES
+#define SESRQ_H5_WAVES 4
+#endif
+// NV (EPI_LAST only): real accumulator rows per lane group, 3 for up to 12 output channels (last_slot_oc, sesrq_common.h)
+template <int MODE, int EPI, int FAST = 0, int NV = 4>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SESRQ_H5_WAVES))) void mfma_h5_kernel(const ConvArgs a) {
     constexpr bool GENERAL = MODE == GEN_STD || MODE == GEN_ANY;
     constexpr int SW = MTW + 8;          // 2 + 64 + 2 halo, + over-read of the kx = 4..7 group
     constexpr int SH = MTH + 4;
-    // planar image [row][PE][col]: plane pitch 78 dwords, row pitch 312 = 24 mod 32 banks.  With the lane groups of a 32-lane
-    // half (the conflict domain of ds_read_b32: lanes 0-31 = groups 0,1; 32-63 = groups 2,3) always TWO image rows apart --
-    // K-chunk 0: groups (0,1,2,3) = kernel rows (0,2,1,3); K-chunk 1: groups (0,1) = translations (0,4),(2,4), groups (2,3) =
-    // (2,0),(2,1) on the same row (overlapping lanes read the same address) -- the two 16-bank windows of a half are 16 banks
-    // apart: no bank conflict on either chunk (round 1: pitch 304, groups = rows 0..3: 2.2 M conflict cycles per launch of
-    // 11 M LDS cycles on the last layer, from the second chunk)
-    constexpr int PW = GENERAL ? SW + 6 : 0;
-    constexpr int RP = 4 * PW;
-    __shared__ int4 buf0[GENERAL ? SH * PW : SH * SW], buf1[GENERAL ? SH * PW : SH * SW];
+    // per-PE (general) kernels: column-major PE-planar image [col][PE][row] (StageNHWC16, CP > 0): plane pitch CP = 13 dwords,
+    // column pitch CS = 54.  A lane's operand per PE and K-chunk = two vertical pixel pairs (h5_pair, sesrq_common.h) = two
+    // ds_read2_b32 of adjacent dwords straight into the four operand registers; all 4 PEs x 8 rows of a tile are reached by
+    // immediate offsets from four lane-constant addresses (one per chunk and pair): no address arithmetic and no operand moves
+    // in the row loop (round 2: [row][PE][col] with a 312-dword row pitch -- 7 address VALU + 6 v_mov per row, because vertically
+    // adjacent pixels were out of ds_read2_b32's offset range).  Banks: the 16 lanes of a group are 54 dwords apart = 16
+    // distinct EVEN banks (22 n mod 32), the two lane groups of a 32-lane half are an odd number of rows apart (h5_pair) = the
+    // odd banks: no conflicts.
+    constexpr int CP = GENERAL ? SH + 1 : 0;
+    constexpr int CS = 4 * CP + 2;
+    __shared__ int4 buf0[GENERAL ? (SW * CS + 3) / 4 : SH * SW], buf1[GENERAL ? (SW * CS + 3) / 4 : SH * SW];
     const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, n = l & 15, g = l >> 4;
     const int x0 = blockIdx.x * MTW, n_img = blockIdx.z;
     const int4 *fr = a.afrag;
@@ -353,18 +393,19 @@ __global__ __launch_bounds__(256) void mfma_h5_kernel(const ConvArgs a) {
     const float zlo = a.relu ? fmaxf(EPI == EPI_LAST ? a.z_out : a.z_next, -128.f) : -128.f;
     const int gx = x0 + 16 * w + n;
     // merged: K-chunks 0..4 = kernel row f, lane group g = kx 0..3;  5 = column 4, lane group g = ky 0..3;  6 = tap (4,4)
-    // general, per PE p two K-chunks:  0: group g = ky 0..3, words = kx 0..3
-    //                                  1: row 4 + column 4: pixel pattern {(0,0),(1,0),(2,0),(2,2)} translated by
-    //                                     (0,4) (2,0) (2,1) (2,4) for lane groups 0..3   (pack_mfma_frags, MFMA_H5)
+    // general, per PE p two K-chunks of two vertical pixel pairs per lane group (h5_pair; pack_mfma_frags, MFMA_H5)
     constexpr int NF = GENERAL ? 8 : 7;
     v4i A[NF];
 #pragma unroll
     for (int f = 0; f < NF; ++f) A[f] = ld_frag(fr + 4 + f * 64 + l);
     // per-PE chains (general, and the risky PE's chain of the hybrid mode); must match pack_mfma_frags (MFMA_H5 general)
-    const int kyg = ((g & 1) << 1) | (g >> 1);          // K-chunk 0: kernel row of lane group g = (0, 2, 1, 3)
-    const int tr1 = (g == 0 ? 0 : 2) * (GENERAL ? RP : SW) + (g < 2 ? 4 : g - 2);    // K-chunk 1 translation of group g: (0,4) (2,4) (2,0) (2,1) (pixels; planar: dwords)
+    int pcol[2][2], prow[2][2];                         // [chunk][pair]: column and first row of lane group g's pixel pair
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) h5_pair(c, g, q, pcol[c][q], prow[c][q]);
     LastStore ls;
-    if constexpr (EPI == EPI_LAST) ls.init(a, n_img, g, gx);
+    if constexpr (EPI == EPI_LAST) ls.template init<NV>(a, n_img, g, gx);
     v4i AR[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
     if constexpr (MODE == HYB) {
         AR[0] = ld_frag(a.afrag2 + 4 + (0 * 4 + a.risky_pe) * 64 + l);
@@ -398,25 +439,35 @@ __global__ __launch_bounds__(256) void mfma_h5_kernel(const ConvArgs a) {
                     acc[0] = mfma(A[5], C5, acc[0]);
                     acc[0] = mfma(A[6], C6, acc[0]);
                     if constexpr (MODE == HYB) {
-                        const int o0 = cb + (y + kyg) * SW * 4;        // K-chunk 0: row y+kyg, columns +0..3
-                        const v4i b0 = {t32[o0], t32[o0 + 4], t32[o0 + 8], t32[o0 + 12]};
-                        const int ob = cb + (y * SW + tr1) * 4;        // K-chunk 1: translated pixel pattern
-                        const v4i b1 = {t32[ob], t32[ob + SW * 4], t32[ob + 2 * SW * 4], t32[ob + (2 * SW + 2) * 4]};
+                        int o[2][2];                                   // word risky_pe of the first pixel of pair [chunk][pair]
+#pragma unroll
+                        for (int c = 0; c < 2; ++c)
+#pragma unroll
+                            for (int q = 0; q < 2; ++q) o[c][q] = cb + ((y + prow[c][q]) * SW + pcol[c][q]) * 4;
+                        const v4i b0 = {t32[o[0][0]], t32[o[0][0] + SW * 4], t32[o[0][1]], t32[o[0][1] + SW * 4]};
+                        const v4i b1 = {t32[o[1][0]], t32[o[1][0] + SW * 4], t32[o[1][1]], t32[o[1][1] + SW * 4]};
                         acc[1] = mfma(AR[0], b0, zero);
                         acc[1] = mfma(AR[1], b1, acc[1]);
                     }
-                    finish_sums<MODE>(s4[r], acc, ac, a);
+                    finish_sums<MODE, NV>(s4[r], acc, ac, a);
                     if constexpr (EPI == EPI_LAST) {
                         // a row below the frame is dropped by its offsets (FAST: the scalar one, else the lanes'), not by a
                         // branch: the four rows stay one basic block
-                        ls.store<BIASED, FAST>(s4[r], a, y0 + y, zlo, y0 + y < a.H);
+                        ls.template store<BIASED, FAST, NV>(s4[r], a, y0 + y, zlo, y0 + y < a.H);
                     }
                 }
                 if constexpr (EPI != EPI_LAST) emit_rows4<EPI, false, BIASED>(s4, a, io, y4, zlo);
             }
         } else {
-            const int col = 16 * w + n;
-#pragma unroll 1
+            typedef int v2iu __attribute__((ext_vector_type(2), aligned(4)));      // two adjacent dwords, dword-aligned: ds_read2_b32
+            typedef const v2iu __attribute__((address_space(3))) *lds_pair_t;
+            const unsigned tb = (unsigned)(size_t)(const __attribute__((address_space(3))) void *)tile;     // LDS byte address of the tile
+            unsigned pb[2][2];                                          // [chunk][pair]: LDS byte address of the pair's first pixel, row 0, PE 0
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+#pragma unroll
+                for (int q = 0; q < 2; ++q) pb[c][q] = tb + ((16 * w + n + pcol[c][q]) * CS + prow[c][q]) * 4;
+#pragma unroll
             for (int y4 = 0; y4 < MTH; y4 += 4) {
                 int s4[4][4];
 #pragma unroll
@@ -424,22 +475,25 @@ __global__ __launch_bounds__(256) void mfma_h5_kernel(const ConvArgs a) {
                     const int y = y4 + r;
                     const v4i zero = {0, 0, 0, 0};
                     v4i acc[4];
-                    const int *tw = reinterpret_cast<const int *>(tile);
-                    const int *c0 = tw + (y + kyg) * RP + col;          // chunk 0: row y+kyg, 4 adjacent pixels
-                    const int *c1 = tw + y * RP + col + tr1;            // chunk 1: translated pattern (0,0) (1,0) (2,0) (2,2)
+                    // the pair of row y + 1 overlaps the pair of row y by one dword: hide the relation between the rows' addresses
+                    // from the compiler, which otherwise loads the shared dword once and then MOVES it into place (8 v_mov per row
+                    // and 168 VGPRs; the reads are not what bounds this loop, vector issue is)
+                    asm("" : "+v"(pb[0][0]), "+v"(pb[0][1]), "+v"(pb[1][0]), "+v"(pb[1][1]));
 #pragma unroll
                     for (int p = 0; p < 4; ++p) {
-                        const int *q0 = c0 + p * PW, *q1 = c1 + p * PW;
-                        const v4i b0 = {q0[0], q0[1], q0[2], q0[3]};
-                        const v4i b1 = {q1[0], q1[RP], q1[2 * RP], q1[2 * RP + 2]};
+                        const int o = y4 + (r + p * CP);
+                        const v2iu a0 = *(lds_pair_t)(size_t)(pb[0][0] + 4 * o), a1 = *(lds_pair_t)(size_t)(pb[0][1] + 4 * o);
+                        const v2iu c0 = *(lds_pair_t)(size_t)(pb[1][0] + 4 * o), c1 = *(lds_pair_t)(size_t)(pb[1][1] + 4 * o);
+                        const v4i b0 = {a0[0], a0[1], a1[0], a1[1]};
+                        const v4i b1 = {c0[0], c0[1], c1[0], c1[1]};
                         acc[p] = mfma(A[p], b0, zero);
                         acc[p] = mfma(A[4 + p], b1, acc[p]);
                     }
-                    finish_sums<MODE>(s4[r], acc, ac, a);
+                    finish_sums<MODE, NV>(s4[r], acc, ac, a);
                     if constexpr (EPI == EPI_LAST) {
                         // a row below the frame is dropped by its offsets (FAST: the scalar one, else the lanes'), not by a
                         // branch: the four rows stay one basic block
-                        ls.store<BIASED, FAST>(s4[r], a, y0 + y, zlo, y0 + y < a.H);
+                        ls.template store<BIASED, FAST, NV>(s4[r], a, y0 + y, zlo, y0 + y < a.H);
                     }
                 }
                 if constexpr (EPI != EPI_LAST) emit_rows4<EPI, false, BIASED>(s4, a, io, y4, zlo);
@@ -447,7 +501,7 @@ __global__ __launch_bounds__(256) void mfma_h5_kernel(const ConvArgs a) {
         }
     };
 #define SESRQ_COMPUTE(B) compute(B, y0);
-    using Stage = StageNHWC16<SH, SW, 2, PW>;
+    using Stage = StageNHWC16<SH, SW, 2, 0, CP>;
     SESRQ_TILE_WALK(Stage, buf0, buf1, SESRQ_COMPUTE)
 #undef SESRQ_COMPUTE
 }
@@ -681,7 +735,8 @@ __device__ __forceinline__ void mfma_f5_body(const ConvArgs &a, int4 *buf0, int4
                 }
                 finish_sums<MODE>(s4[r], acc, ac, a);
             }
-            emit_rows4<EPI_MID, RC, BIASED>(s4, a, io, y4, zlo);
+            // no separate residual tensor <=> zero[1] == -128 (sesrq_create) <=> this layer's z_next == -128: the cvt_pk_u8 epilogue
+            emit_rows4<EPI_MID, RC, BIASED, !RC && SESRQ_U8>(s4, a, io, y4, zlo);
         }
     };
 #define SESRQ_COMPUTE(B) compute(B, y0);
@@ -695,7 +750,10 @@ __device__ __forceinline__ void mfma_f5_body(const ConvArgs &a, int4 *buf0, int4
 // first output word was garbage in lanes 28..31 (caught by the satw_zeros golden vectors; the same source without the
 // attribute, or with unrelated extra code in the loop, is correct) -- those take the registers they ask for.
 template <int MODE, int SRC, bool RC, int NCH>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void mfma_f5_kernel_w4(const ConvArgs a) {
+#ifndef SESRQ_F5_WAVES
+#define SESRQ_F5_WAVES 4
+#endif
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SESRQ_F5_WAVES))) void mfma_f5_kernel_w4(const ConvArgs a) {
     __shared__ int4 buf0[F5_SH * F5_PITCH / 4], buf1[F5_SH * F5_PITCH / 4];      // SH rows of 4-byte pixels
     mfma_f5_body<MODE, SRC, RC, NCH>(a, buf0, buf1);
 }
@@ -777,6 +835,10 @@ int launch_mfma(const LayerPlan &lp, const ConvArgs &a_in, int src, int epi, boo
             }
             if (epi == EPI_MID) SESRQ_BY_MODE(mfma_h5_kernel, EPI_MID);
             else if (epi == EPI_PRERES) SESRQ_BY_MODE(mfma_h5_kernel, EPI_PRERES);
+            else if (last_nv(a.oc) == 3) {       // up to 12 output channels: three real rows per lane group (must match pack_mfma_frags)
+                if (a.out_q && !a.out_f && last_pairmap(a.oc, a.ps)) SESRQ_BY_MODE(mfma_h5_kernel, EPI_LAST, 2, 3);
+                else SESRQ_BY_MODE(mfma_h5_kernel, EPI_LAST, 0, 3);
+            }
             else if (a.out_q && !a.out_f && a.ps == 2) SESRQ_BY_MODE(mfma_h5_kernel, EPI_LAST, 2);
             else if (a.out_q && !a.out_f && a.ps == 4) SESRQ_BY_MODE(mfma_h5_kernel, EPI_LAST, 4);
             else SESRQ_BY_MODE(mfma_h5_kernel, EPI_LAST);

@@ -9,6 +9,10 @@ typedef unsigned v4u __attribute__((ext_vector_type(4)));
 typedef unsigned v2u __attribute__((ext_vector_type(2)));
 typedef float v2f __attribute__((ext_vector_type(2)));
 
+#ifndef SESRQ_U8
+#define SESRQ_U8 1      /* A/B knob: 0 = med3 + magic add + perm epilogue everywhere (round_pack), 1 = round_pack_u8 where every zero point is -128 */
+#endif
+
 constexpr float MAGIC = 12582912.f;   // 1.5 * 2^23
 
 // accumulate modes
@@ -58,6 +62,17 @@ __device__ __forceinline__ v4i gather4(const int4 a, const int4 b, const int4 c,
     return r;
 }
 
+// A wave-uniform float pinned to a VGPR.  hipcc 7.2 (clang 22) un-packs a v_pk_fma_f32 that sits in the shadow of an MFMA into two
+// v_fma_f32; when the packed form read BOTH scalar operands out of one SGPR pair (s[n:n+1] with op_sel: 2^-n and the zero point
+// happen to be neighbours in the kernel arguments) the two halves become fma(v, s[n], s[n+1]) -- two scalar operands, illegal on
+// gfx9 ("VOP* instruction violates constant bus restriction", caught by the assembler printer, so a build error, never silent).
+// The requant's additive constant therefore travels in a VGPR wherever the register allocation made that pairing.
+__device__ __forceinline__ float in_vgpr(float x) {
+    float r;
+    asm("v_mov_b32 %0, %1" : "=v"(r) : "s"(x));
+    return r;
+}
+
 // low bytes of four words -> one word
 __device__ __forceinline__ unsigned pack_lo_bytes(unsigned y0, unsigned y1, unsigned y2, unsigned y3) {
     const unsigned w01 = __builtin_amdgcn_perm(y1, y0, 0x0c0c0400u);
@@ -73,7 +88,8 @@ constexpr int MAGIC_I = 0x4B400000;   // bit pattern of MAGIC: int s (|s| < 2^22
 // representable (3*M < 2^18), so the single rounding is that of the exact s*M -- no v_cvt_f32_i32.
 template <bool BIASED>
 __device__ __forceinline__ void requant4(const int s[4], float Mf, float sh, float zadd, v2f &v01, v2f &v23) {
-    const v2f M2 = {Mf, Mf}, sh2 = {sh, sh}, z2 = {zadd, zadd};
+    const float zv = in_vgpr(zadd);       // see in_vgpr(): one v_mov per call site, hoisted out of the row loops
+    const v2f M2 = {Mf, Mf}, sh2 = {sh, sh}, z2 = {zv, zv};
     if constexpr (BIASED) {
         const float c = -(MAGIC * Mf);
         const v2f c2 = {c, c};
@@ -96,12 +112,33 @@ __device__ __forceinline__ unsigned round_pack(v2f v01, v2f v23, float lo, float
     return pack_lo_bytes(fbits(c01[0]), fbits(c01[1]), fbits(c23[0]), fbits(c23[1]));
 }
 
+// The same for a value that already carries the zero point -128, v = fl(t - 128): one v_cvt_pk_u8_f32 per value does the clamp,
+// the round-to-nearest-even and the byte insertion -- clamp8(rint(v)) + 128 == cvt_u8(fl(v + 128)) for EVERY fp32 t
+// (exhaustive: tools/cvtpk_epilogue_probe.hip; v lies on the grid of t - 128, so v + 128 is exact where it matters) -- and one
+// xor per word takes the four bytes back to two's complement: 2 pk_add + 4 cvt + 1 xor instead of 4 med3 + 2 pk_add + 3 perm.
+// Only for the zero point -128 (every net calibrated on non-negative activations: all reference bundles), where ReLU's lower
+// clamp max(z, -128) is the int8 clamp itself.
+__device__ __forceinline__ unsigned round_pack_u8(v2f v01, v2f v23) {
+    const v2f k = {128.f, 128.f};
+    v01 = v01 + k; v23 = v23 + k;
+    unsigned w = __builtin_amdgcn_cvt_pk_u8_f32(v01[0], 0, 0u);
+    w = __builtin_amdgcn_cvt_pk_u8_f32(v01[1], 1, w);
+    w = __builtin_amdgcn_cvt_pk_u8_f32(v23[0], 2, w);
+    w = __builtin_amdgcn_cvt_pk_u8_f32(v23[1], 3, w);
+    return w ^ 0x80808080u;
+}
+
 // ---- epilogues (AT = any struct with the ConvArgs field names Mf, sh, z_next, Mres, shres, z_merge) ----
+// U8: every zero point the epilogue adds is -128 (z_next; for the residual merge also z_merge): round_pack_u8
 
 // hidden layer: q = clamp8(rint(relu(t) + z_next))            (myQL/quan_func.py:280)
-template <bool BIASED, class AT>
+template <bool BIASED, bool U8 = false, class AT>
 __device__ __forceinline__ unsigned epi_mid(const int s[4], const AT &a, float zlo) {
     v2f v01, v23;
+    if constexpr (U8) {
+        requant4<BIASED>(s, a.Mf, a.sh, -128.f, v01, v23);
+        return round_pack_u8(v01, v23);
+    }
     requant4<BIASED>(s, a.Mf, a.sh, a.z_next, v01, v23);
     return round_pack(v01, v23, zlo, 127.f);
 }
@@ -113,7 +150,7 @@ __device__ __forceinline__ unsigned epi_rc(const int s[4], const AT &a) {
     return round_pack(v01, v23, -128.f, 127.f);
 }
 // layer L-2: long residual merged in the integer domain        (myQL/quan_func.py:249-270)
-template <bool BIASED, class AT>
+template <bool BIASED, bool U8 = false, class AT>
 __device__ __forceinline__ unsigned epi_preres(const int s[4], unsigned rcword, const AT &a) {
     v2f v01, v23;
     requant4<BIASED>(s, a.Mf, a.sh, -128.f, v01, v23);
@@ -128,16 +165,21 @@ __device__ __forceinline__ unsigned epi_preres(const int s[4], unsigned rcword, 
     const int u[4] = {(int)(fbits(c01[0]) + (rcx & 0xffu)), (int)(fbits(c01[1]) + ((rcx >> 8) & 0xffu)),
                       (int)(fbits(c23[0]) + ((rcx >> 16) & 0xffu)), (int)(fbits(c23[1]) + (rcx >> 24))};
     v2f w01, w23;
+    if constexpr (U8) {
+        requant4<true>(u, a.Mres, a.shres, -128.f, w01, w23);
+        return round_pack_u8(w01, w23);
+    }
     requant4<true>(u, a.Mres, a.shres, a.z_merge, w01, w23);
     return round_pack(w01, w23, -128.f, 127.f);
 }
 
 // PE clamp / sum / adder clamp / add constant               (myQL/quan_func.py:370,380-386,437,491)
-template <int MODE, class AT>
+// NV: real rows of the lane (the last layer's three-row map leaves s[3] untouched: padding, never read)
+template <int MODE, int NV = 4, class AT>
 __device__ __forceinline__ void finish_sums(int s[4], const v4i *acc, const int4 ac, const AT &a) {
     const int acv[4] = {ac.x, ac.y, ac.z, ac.w};
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < NV; ++i) {
         if constexpr (MODE == MERGED) {
             s[i] = acc[0][i];       // add constant already in the accumulator (C-in)
         } else if constexpr (MODE == HYB) {
@@ -194,7 +236,7 @@ __device__ __forceinline__ void store_rows4(__amdgpu_buffer_rsrc_t rs, const Row
 }
 
 // hidden-layer output of 4 rows: s4[r][i] -> requant -> transpose -> one 16-byte store per lane
-template <int EPI, bool RC, bool BIASED, class AT>
+template <int EPI, bool RC, bool BIASED, bool U8 = false, class AT>
 __device__ __forceinline__ void emit_rows4(const int s4[4][4], const AT &a, const RowIO &io, int y4, float zlo) {
     unsigned w[4];
     if constexpr (EPI == EPI_PRERES) {
@@ -202,10 +244,10 @@ __device__ __forceinline__ void emit_rows4(const int s4[4][4], const AT &a, cons
         unsigned rcw[4] = {rv[0], rv[1], rv[2], rv[3]};
         transpose4(rcw);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) w[r] = epi_preres<BIASED>(s4[r], rcw[r], a);
+        for (int r = 0; r < 4; ++r) w[r] = epi_preres<BIASED, U8>(s4[r], rcw[r], a);
     } else {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) w[r] = epi_mid<BIASED>(s4[r], a, zlo);
+        for (int r = 0; r < 4; ++r) w[r] = epi_mid<BIASED, U8>(s4[r], a, zlo);
     }
     store_rows4(io.out, io, y4, w);
     if constexpr (RC) {

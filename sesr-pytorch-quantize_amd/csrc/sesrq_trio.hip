@@ -89,7 +89,8 @@ struct TrioEpiC {           // the field names the shared epilogues read
     float Mf, sh, z_next, Mres, shres, z_merge;
 };
 
-template <int EPI_C>
+// U8: every zero point of the three epilogues is -128 (the launch checks): round_pack_u8 (sesrq_mfma_common.h)
+template <int EPI_C, bool U8>
 __global__ __launch_bounds__(256) void mfma_trio_kernel(const TrioArgs a) {
     extern __shared__ int4 trio_lds[];             // dynamic: the launch pads the size so that exactly `occ` workgroups fit a CU
     int4 *bufI = trio_lds, *bufA = trio_lds + TRIO_WIN, *bufB = trio_lds + 2 * TRIO_WIN;
@@ -149,7 +150,7 @@ __global__ __launch_bounds__(256) void mfma_trio_kernel(const TrioArgs a) {
             acc = mfma(A[K][2], B2, acc);
             B0 = B1; B1 = B2;
             const int s[4] = {acc[0], acc[1], acc[2], acc[3]};
-            unsigned q = epi_mid<true>(s, L, L.zlo);
+            unsigned q = epi_mid<true, U8>(s, L, L.zlo);
             const int row = row0 + i;
             const bool rok = (row >= 0) & (row < a.H);
             q = (rok & col_in) ? q : (unsigned)L.pad_next;
@@ -175,7 +176,7 @@ __global__ __launch_bounds__(256) void mfma_trio_kernel(const TrioArgs a) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) s4[r][i] = acc[i];
             }
-            emit_rows4<EPI_C, false, true>(s4, ec, io, y4, a.l[2].zlo);
+            emit_rows4<EPI_C, false, true, U8>(s4, ec, io, y4, a.l[2].zlo);
         }
     };
     using std::integral_constant;
@@ -271,8 +272,13 @@ static void launch_trio_k(K kern, TrioArgs a, hipStream_t st) {
 
 int launch_trio(const TrioArgs &a, int epi_c, hipStream_t st) {
     if ((size_t)a.H * a.W * 16 >= ((size_t)1 << 28)) { set_error("trio: frame too large for 32-bit buffer offsets (H*W must stay below 2^24 pixels)"); return 1; }
-    if (epi_c == EPI_PRERES) launch_trio_k(mfma_trio_kernel<EPI_PRERES>, a, st);
-    else if (epi_c == EPI_MID) launch_trio_k(mfma_trio_kernel<EPI_MID>, a, st);
+    // zero points all -128 (and ReLU's clamp therefore the int8 clamp): the cvt_pk_u8 epilogues
+    bool u8 = a.l[0].z_next == -128.f && a.l[1].z_next == -128.f && a.l[0].zlo == -128.f && a.l[1].zlo == -128.f;
+    if (epi_c == EPI_PRERES) u8 = u8 && a.z_merge == -128.f;
+    else u8 = u8 && a.l[2].z_next == -128.f && a.l[2].zlo == -128.f;
+    if (!SESRQ_U8) u8 = false;                     // A/B build knob
+    if (epi_c == EPI_PRERES) { if (u8) launch_trio_k(mfma_trio_kernel<EPI_PRERES, true>, a, st); else launch_trio_k(mfma_trio_kernel<EPI_PRERES, false>, a, st); }
+    else if (epi_c == EPI_MID) { if (u8) launch_trio_k(mfma_trio_kernel<EPI_MID, true>, a, st); else launch_trio_k(mfma_trio_kernel<EPI_MID, false>, a, st); }
     else { set_error("trio: the third layer must be a hidden layer"); return 1; }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { set_error(std::string("trio launch failed: ") + hipGetErrorString(e)); return 1; }
