@@ -132,17 +132,18 @@ static void pack_mfma_frags(const sesrq_layer_desc &d, int kind, bool general, i
                     if ((b >> 2) != (m >> 2)) ky = -1;              // byte group i = PE of the channel
                 } else if (kind == MFMA_F5) {
                     // K-chunk 0: lane group g = kernel row g, dwords = kx 0..3.  K-chunk 1: the 9 remaining taps (row 4 and
-                    // column 4) are covered by FOUR translates of ONE 4-pixel pattern {(0,0),(1,0),(2,0),(2,2)}, so a single
+                    // column 4) are covered by FOUR translates f5_tr(g) of ONE 4-pixel pattern f5_pt(i) (sesrq_common.h), so a single
                     // pair of ds_read2_b32 (same immediate offsets in every lane) fetches every lane group's operand.
                     const int npe = general ? 4 : 1, fi = f / npe, p = f % npe;
-                    static const int tr[4][2] = {{0, 4}, {2, 0}, {2, 1}, {2, 4}};       // (row, column) translation of lane group g
-                    static const int pt[4][2] = {{0, 0}, {1, 0}, {2, 0}, {2, 2}};       // the pattern, dword i
                     ch = j;
                     if (fi == 0) { ky = g; kx = i; }
                     else {
-                        ky = tr[g][0] + pt[i][0]; kx = tr[g][1] + pt[i][1];
+                        int tr_r, tr_c, pt_r, pt_c;
+                        f5_tr(g, tr_r, tr_c);
+                        f5_pt(i, pt_r, pt_c);
+                        ky = tr_r + pt_r; kx = tr_c + pt_c;
                         const bool in_l = (ky == 4 && kx <= 4) || (kx == 4 && ky <= 4);   // taps not in K-chunk 0
-                        const bool dup = (g == 3 && i == 0);                              // (2,4) belongs to lane group 0
+                        const bool dup = (g == 2 && i == 1);                              // (4,2) belongs to lane group 0
                         if (!in_l || dup) ky = -1;
                     }
                     if (general && ch != p) ky = -1;

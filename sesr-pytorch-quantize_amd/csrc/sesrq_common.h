@@ -23,6 +23,16 @@ inline void launch_kernel(K kern, dim3 grid, dim3 block, unsigned lds, hipStream
 
 enum Epi { EPI_MID = 0, EPI_PRERES = 1, EPI_LAST = 2 };
 
+// First layer (MFMA_F5 images; kernels: mfma_f5_kernel, mfma_quad_kernel): a pixel is one dword (byte c = channel c).  K-chunk 0 = the
+// 4x4 block of taps (lane group g = kernel row g, dwords = kx 0..3); K-chunk 1 = the 9 taps of kernel row 4 and column 4, covered
+// by four translates f5_tr(g) of ONE 4-pixel pattern {(0,0),(1,0),(1,1),(1,2)}: the two lane groups of a 32-lane half are an odd
+// number of rows apart (3|0 and 3|2), which the column-major LDS image of mfma_f5_kernel needs for conflict-free dword reads.
+__host__ __device__ inline void f5_tr(int g, int &row, int &col) {
+    row = (g == 0 || g == 2) ? 3 : (g == 1 ? 0 : 2);
+    col = g == 0 ? 0 : (g == 2 ? 2 : 4);
+}
+__host__ __device__ inline void f5_pt(int i, int &row, int &col) { row = i == 0 ? 0 : 1; col = i < 2 ? 0 : i - 1; }
+
 // 5x5 per-PE chains (MFMA_H5 general image; kernels: mfma_h5_kernel).  A lane's 16 operand bytes per PE and K-chunk are TWO
 // VERTICAL PAIRS of pixels: K-chunk c, lane group g, pair q covers the taps (ky = start, start + 1; kx = col) of
 // h5_pair(c, g, q).  In the column-major planar LDS image (sesrq_mfma.hip) a vertical pair is two adjacent dwords = one

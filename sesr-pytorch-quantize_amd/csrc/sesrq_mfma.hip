@@ -590,9 +590,10 @@ __global__ __launch_bounds__(256) void mfma_h5p_kernel(const ConvArgs a) {
 
 // ------------------------------------------------------------------ first layer 5x5, IC <= 4
 // The frame is quantised while it is staged (q0 = clamp8(rint(x/s0 + z0)), quan_func.py:225);
-// a pixel is one dword (byte c = channel c).  A lane's 16 bytes = 4 horizontally adjacent pixels
-// starting at an arbitrary pixel column: read as dwords (ds_read2_b32 pairs), which have no 16-byte
-// alignment requirement -- one copy of the tile in LDS, one ds_write_b32 per staged pixel.
+// a pixel is one dword (byte c = channel c), the LDS image is COLUMN-major (dword [column][row], column pitch 18 = 2 mod 4):
+// every operand dword of every row of a tile lies within ds_read2_b32's 8-bit dword offsets of two lane-constant addresses
+// (round 2: row-major with an 80-dword pitch -- 4 address VALU + 2 operand moves per row), the 16 lanes of a group sit on 16
+// distinct even banks and the two lane groups of a 32-lane half an odd number of rows apart, i.e. on the odd banks.
 // NCH: input channels as a compile-time count (1 and 3 are the reference's nets), or 4 = "a.ic of them, tested per channel":
 // the wave-uniform test put every channel's load and quantise code into a block of its own.
 template <int SRC, int SH, int SWP, int PITCH, int NCH>
@@ -660,7 +661,7 @@ struct StageFrame {
             }
             int word = (int)pack_lo_bytes(b[0], b[1], b[2], b[3]);
             if (!ok[it]) word = a.pad_word;
-            if (i < SH * SWP) cpw[(i / SWP) * PITCH + (i % SWP)] = word;
+            if (i < SH * SWP) cpw[(i % SWP) * PITCH + (i / SWP)] = word;      // column-major: dword [column][row], column pitch PITCH
         }
     }
 };
@@ -671,8 +672,8 @@ struct StageFrame {
 constexpr int F5_TH = SESRQ_F5_TH;      // first-layer tile height (rows)
 constexpr int F5_SH = F5_TH + 4;
 constexpr int F5_SWP = MTW + 8;         // staged pixel columns (2 halo + 64 + 2 halo + over-read)
-constexpr int F5_PITCH = F5_SWP + 8;    // LDS row pitch in pixels: 16 dwords mod 32, so the four lane groups of an
-                                        // operand read (rows g, g+1, ...) hit disjoint banks
+constexpr int F5_PITCH = F5_SH + 2;     // LDS column pitch in dwords (>= rows, = 2 mod 4)
+static_assert(F5_PITCH % 4 == 2 && 3 * F5_PITCH + F5_SH < 256, "column pitch: bank rule / ds_read2_b32 offset range");
 template <int MODE, int SRC, bool RC, int NCH>
 __device__ __forceinline__ void mfma_f5_body(const ConvArgs &a, int4 *buf0, int4 *buf1) {
     constexpr bool GENERAL = MODE == GEN_STD || MODE == GEN_ANY;
@@ -695,27 +696,37 @@ __device__ __forceinline__ void mfma_f5_body(const ConvArgs &a, int4 *buf0, int4
         for (int f = 0; f < 2; ++f) AR[f] = ld_frag(a.afrag2 + 4 + (f * 4 + a.risky_pe) * 64 + l);
     }
     // lane group -> first pixel of its operand per K-chunk; must match pack_mfma_frags (MFMA_F5)
-    //   chunk 0: row g, 4 horizontally adjacent pixels          (dwords +0 +1 +2 +3)
-    //   chunk 1: pattern {(0,0),(1,0),(2,0),(2,2)} translated by (0,4) (2,0) (2,1) (2,4)   (dwords +0 +P +2P +2P+2)
-    int addr[2];
-    {
-        const int tr_r = g == 0 ? 0 : 2, tr_c = g == 0 ? 4 : (g == 1 ? 0 : (g == 2 ? 1 : 4));
-        addr[0] = g * PITCH + 16 * w + n;
-        addr[1] = tr_r * PITCH + 16 * w + n + tr_c;
-    }
+    //   chunk 0: row g, 4 horizontally adjacent pixels          (dwords +0 +P +2P +3P, P = column pitch)
+    //   chunk 1: pattern {(0,0),(1,0),(1,1),(1,2)} translated by f5_tr(g)   (dwords +0 +1 +1+P +1+2P)
+    int tr_r, tr_c;
+    f5_tr(g, tr_r, tr_c);
+    const int addr0 = ((16 * w + n) * PITCH + g) * 4, addr1 = ((16 * w + n + tr_c) * PITCH + tr_r) * 4;     // bytes
     const float zlo = a.relu ? fmaxf(a.z_next, -128.f) : -128.f;
     const int gx = x0 + 16 * w + n;
+    // hybrid: s = (add constant + the three safe PEs) + clamp18(risky PE).  The risky PE's chain runs FIRST with the add constant as
+    // its C input, is clamped against per-row bounds shifted by that constant, and is then the C input of the other chain: one
+    // v_med3_i32 per value instead of a clamp and an add.
+    int rlo[4], rhi[4];
+    {
+        const int acv[4] = {ac.x, ac.y, ac.z, ac.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { rlo[i] = acv[i] - 131072; rhi[i] = acv[i] + 131071; }
+    }
     auto compute = [&](const int4 *cp, int y0) __attribute__((always_inline)) {
         const RowIO io = make_rowio(a, n_img, y0, gx, g);
-        const int *cpw = reinterpret_cast<const int *>(cp);
+        typedef const int __attribute__((address_space(3))) *lds_int_t;
+        const unsigned tb = (unsigned)(size_t)(const __attribute__((address_space(3))) void *)cp;     // LDS byte address of the tile
+        unsigned b0 = tb + addr0, b1 = tb + addr1;
 #pragma unroll 1
         for (int y4 = 0; y4 < F5_TH; y4 += 4) {
             int s4[4][4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int y = y4 + r;
-                const int *p0 = cpw + addr[0] + y * PITCH, *p1 = cpw + addr[1] + y * PITCH;
-                const v4i B0 = {p0[0], p0[1], p0[2], p0[3]}, B1 = {p1[0], p1[PITCH], p1[2 * PITCH], p1[2 * PITCH + 2]};
+                // vertically adjacent pixels are adjacent dwords: keep the compiler from recognising that row y + 1 re-reads dwords of
+                // row y -- it would load them once and MOVE them into the next operand (the reads are not what bounds this loop)
+                asm("" : "+v"(b0), "+v"(b1));
+                const lds_int_t p0 = (lds_int_t)(size_t)(b0 + 4 * r), p1 = (lds_int_t)(size_t)(b1 + 4 * r);
+                const v4i B0 = {p0[0], p0[PITCH], p0[2 * PITCH], p0[3 * PITCH]}, B1 = {p1[0], p1[1], p1[1 + PITCH], p1[1 + 2 * PITCH]};
                 v4i acc[GENERAL ? 4 : (MODE == HYB ? 2 : 1)];
                 const v4i zero = {0, 0, 0, 0};
                 if constexpr (GENERAL) {
@@ -724,19 +735,27 @@ __device__ __forceinline__ void mfma_f5_body(const ConvArgs &a, int4 *buf0, int4
                         acc[p] = mfma(A[0][p], B0, zero);
                         acc[p] = mfma(A[1][p], B1, acc[p]);
                     }
+                    finish_sums<MODE>(s4[r], acc, ac, a);
                 } else {
                     const v4i acc0 = {ac.x, ac.y, ac.z, ac.w};
-                    acc[0] = mfma(A[0][0], B0, acc0);
-                    acc[0] = mfma(A[1][0], B1, acc[0]);
                     if constexpr (MODE == HYB) {       // same B operands, A masked to the risky PE's channel
-                        acc[1] = mfma(AR[0], B0, zero);
-                        acc[1] = mfma(AR[1], B1, acc[1]);
+                        v4i rk = mfma(AR[0], B0, acc0);
+                        rk = mfma(AR[1], B1, rk);
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) rk[i] = med3_biased(rk[i], rlo[i], rhi[i]);
+                        acc[0] = mfma(A[0][0], B0, rk);
+                        acc[0] = mfma(A[1][0], B1, acc[0]);
+                    } else {
+                        acc[0] = mfma(A[0][0], B0, acc0);
+                        acc[0] = mfma(A[1][0], B1, acc[0]);
                     }
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) s4[r][i] = acc[0][i];
                 }
-                finish_sums<MODE>(s4[r], acc, ac, a);
             }
             // no separate residual tensor <=> zero[1] == -128 (sesrq_create) <=> this layer's z_next == -128: the cvt_pk_u8 epilogue
             emit_rows4<EPI_MID, RC, BIASED, !RC && SESRQ_U8>(s4, a, io, y4, zlo);
+            b0 += 16; b1 += 16;
         }
     };
 #define SESRQ_COMPUTE(B) compute(B, y0);
@@ -754,12 +773,12 @@ template <int MODE, int SRC, bool RC, int NCH>
 #define SESRQ_F5_WAVES 4
 #endif
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SESRQ_F5_WAVES))) void mfma_f5_kernel_w4(const ConvArgs a) {
-    __shared__ int4 buf0[F5_SH * F5_PITCH / 4], buf1[F5_SH * F5_PITCH / 4];      // SH rows of 4-byte pixels
+    __shared__ int4 buf0[(F5_SWP * F5_PITCH + 3) / 4], buf1[(F5_SWP * F5_PITCH + 3) / 4];      // SH rows of 4-byte pixels
     mfma_f5_body<MODE, SRC, RC, NCH>(a, buf0, buf1);
 }
 template <int MODE, int SRC, bool RC, int NCH>
 __global__ __launch_bounds__(256) void mfma_f5_kernel(const ConvArgs a) {
-    __shared__ int4 buf0[F5_SH * F5_PITCH / 4], buf1[F5_SH * F5_PITCH / 4];
+    __shared__ int4 buf0[(F5_SWP * F5_PITCH + 3) / 4], buf1[(F5_SWP * F5_PITCH + 3) / 4];
     mfma_f5_body<MODE, SRC, RC, NCH>(a, buf0, buf1);
 }
 

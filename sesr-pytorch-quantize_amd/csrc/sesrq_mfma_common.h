@@ -21,6 +21,13 @@ enum { MERGED = 0, GEN_STD = 1, GEN_ANY = 2, HYB = 3 };   // GEN_STD: 18/20-bit 
 __device__ __forceinline__ v4i mfma(v4i a, v4i b, v4i c) { return __builtin_amdgcn_mfma_i32_16x16x64_i8(a, b, c, 0, 0, 0); }
 __device__ __forceinline__ float med3(float v, float lo, float hi) { return __builtin_amdgcn_fmed3f(v, lo, hi); }
 __device__ __forceinline__ int clampi3(int v, int lo, int hi) { return min(max(v, lo), hi); }
+// the same for BIASED sums (bits = MAGIC_I + s = the float 1.5 * 2^23 + s, |s| < 2^22: one binade, so float order == integer order)
+// with bounds that are not compile-time constants: one v_med3_f32 on the bit patterns.  (hipcc forms v_med3_i32 only for constant
+// bounds -- v_max + v_min otherwise -- and an inline-asm v_med3_i32 would read an MFMA result without the wait states the compiler
+// only inserts for instructions it models: 5617 wrong values in the first test.)
+__device__ __forceinline__ int med3_biased(int v, int lo, int hi) {
+    return __builtin_bit_cast(int, __builtin_amdgcn_fmed3f(__builtin_bit_cast(float, v), __builtin_bit_cast(float, lo), __builtin_bit_cast(float, hi)));
+}
 __device__ __forceinline__ v4i ld_frag(const int4 *p) { const int4 t = *p; v4i r = {t.x, t.y, t.z, t.w}; return r; }
 __device__ __forceinline__ unsigned fbits(float f) { return __builtin_bit_cast(unsigned, f); }
 
@@ -67,9 +74,14 @@ __device__ __forceinline__ v4i gather4(const int4 a, const int4 b, const int4 c,
 // happen to be neighbours in the kernel arguments) the two halves become fma(v, s[n], s[n+1]) -- two scalar operands, illegal on
 // gfx9 ("VOP* instruction violates constant bus restriction", caught by the assembler printer, so a build error, never silent).
 // The requant's additive constant therefore travels in a VGPR wherever the register allocation made that pairing.
+// The s_nop is part of the contract of writing a VGPR from inline asm: hipcc pads hazards only for instructions it models, and it
+// placed this v_mov directly behind a buffer_store_dwordx4 whose first data register it re-used as the destination -- the store
+// then read the overwritten register ("VMEM store of more than 64 bits -> write of its data VGPRs" needs 2 wait states): word 0 of
+// some stored pixels was garbage, different from run to run (found by the 4K-frame test on the general first-layer kernel; the
+// same signature as round 2's "waves_per_eu(4) miscompile" of that kernel, whose first output word was garbage in some lanes).
 __device__ __forceinline__ float in_vgpr(float x) {
     float r;
-    asm("v_mov_b32 %0, %1" : "=v"(r) : "s"(x));
+    asm("s_nop 1\n\tv_mov_b32 %0, %1" : "=v"(r) : "s"(x));
     return r;
 }
 

@@ -180,8 +180,9 @@ __global__ __launch_bounds__(256) void mfma_quad_kernel(const QuadArgs a) {
 
     // ---- phase 0: first layer, RAW positions i .. i+4 -> IN position 3+i, rows i = 2w, 2w+1 of this wave, five column groups
     // lane group -> first pixel of its operand per K-chunk (must match pack_mfma_frags, MFMA_F5):
-    //   chunk 0: row g, 4 horizontally adjacent pixels;  chunk 1: pattern {(0,0),(1,0),(2,0),(2,2)} translated by (0,4) (2,0) (2,1) (2,4)
-    const int tr_r = g == 0 ? 0 : 2, tr_c = g == 0 ? 4 : (g == 1 ? 0 : (g == 2 ? 1 : 4));
+    //   chunk 0: row g, 4 horizontally adjacent pixels;  chunk 1: pattern {(0,0),(1,0),(1,1),(1,2)} translated by f5_tr(g)
+    int tr_r, tr_c;
+    f5_tr(g, tr_r, tr_c);
     const int a0 = g * QRP + n, a1 = tr_r * QRP + n + tr_c;
     unsigned colmask = 0;                 // bit gi: window column 16*gi + n is inside the frame
 #pragma unroll
@@ -193,7 +194,7 @@ __global__ __launch_bounds__(256) void mfma_quad_kernel(const QuadArgs a) {
     auto item0 = [&](const int *p0, const int *p1, const v4i &F0, const v4i &F1, const v4i &R0, const v4i &R1, const v4i &ac,
                      const int4 &aci, bool keep, bool wr, unsigned *dst) __attribute__((always_inline)) {
         const v4i zero = {0, 0, 0, 0};
-        const v4i B0 = {p0[0], p0[1], p0[2], p0[3]}, B1 = {p1[0], p1[QRP], p1[2 * QRP], p1[2 * QRP + 2]};
+        const v4i B0 = {p0[0], p0[1], p0[2], p0[3]}, B1 = {p1[0], p1[QRP], p1[QRP + 1], p1[QRP + 2]};
         v4i acc[2];
         acc[0] = mfma(F0, B0, ac);
         acc[0] = mfma(F1, B1, acc[0]);

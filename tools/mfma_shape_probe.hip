@@ -5,6 +5,7 @@
 //   a16pipe : the chain of row i+1 interleaved with the epilogue of row i (two accumulators)
 //   b32     : 6 dependent v_mfma_i32_32x32x32_i8 (2 rows x 32 pixels = 4 rows of a16) -> 4 epilogues
 //   b32cvt  : same with the 11-instruction epilogue
+//   chain / epi13 : the three MFMAs alone / the 13 instructions alone;  a16indep: three independent MFMAs + the epilogue
 // Reported: ns per 16-pixel row per SIMD at 1..4 waves per SIMD (work per row is identical across variants).
 //   hipcc --offload-arch=gfx950 -O2 tools/mfma_shape_probe.hip -o /tmp/msp && /tmp/msp
 #include <hip/hip_runtime.h>
@@ -35,7 +36,8 @@ typedef int v16i __attribute__((ext_vector_type(16)));
       CVT(w, p[0], 0) CVT(w, p[1], 1) CVT(w, q[0], 2) CVT(w, q[1], 3) XOR(w) }
 
 template <int KIND>
-__global__ __launch_bounds__(256) void k(unsigned *out, int iters, float mf, float sh) {
+__global__ __launch_bounds__(256) void k(unsigned *out, int iters, float mf, float sh, unsigned long long *clk) {
+    const unsigned long long t0c = __builtin_amdgcn_s_memtime(), t0r = __builtin_amdgcn_s_memrealtime();
     const v4i A = {(int)threadIdx.x, 2, 3, 4}, B = {5, (int)threadIdx.x, 7, 8};
     const v2f m2 = {mf, mf}, c2 = {-mf, -mf}, s2 = {sh, sh}, z2 = {-128.f, -128.f}, g2 = {12582912.f, 12582912.f};
     const float lo = -128.f, hi = 127.f;
@@ -68,6 +70,30 @@ __global__ __launch_bounds__(256) void k(unsigned *out, int iters, float mf, flo
             keep ^= w;
             cur = nxt;
         }
+    } else if constexpr (KIND == 5) {                  // the chain alone
+        const v4i zero = {0, 0, 0, 0};
+        for (int i = 0; i < iters; ++i) {
+            v4i acc;
+            MFMA16(acc, zero) MFMA16A(acc) MFMA16A(acc)
+            keep ^= (unsigned)acc[0];
+        }
+    } else if constexpr (KIND == 6) {                  // the 13-instruction epilogue alone
+        v2f p = {1.f, 2.f}, q = {3.f, 4.f};
+        for (int i = 0; i < iters; ++i) {
+            unsigned w = 0;
+            EPI13(p, q, w)
+            keep ^= w;
+        }
+    } else if constexpr (KIND == 7) {                  // three INDEPENDENT MFMAs + epilogue (is the chain's dependency what costs?)
+        const v4i zero = {0, 0, 0, 0};
+        for (int i = 0; i < iters; ++i) {
+            v4i acc, acc2, acc3;
+            MFMA16(acc, zero) MFMA16(acc2, zero) MFMA16(acc3, zero)
+            v2f p = {__builtin_bit_cast(float, acc[0]), __builtin_bit_cast(float, acc2[1])}, q = {__builtin_bit_cast(float, acc3[2]), __builtin_bit_cast(float, acc[3])};
+            unsigned w = 0;
+            EPI13(p, q, w)
+            keep ^= w;
+        }
     } else {                                            // b32 / b32cvt: 2 rows x 32 pixels = 4 a16 rows per iteration
         v16i zero;
         for (int j = 0; j < 16; ++j) zero[j] = 0;
@@ -84,6 +110,10 @@ __global__ __launch_bounds__(256) void k(unsigned *out, int iters, float mf, flo
         }
     }
     out[blockIdx.x * blockDim.x + threadIdx.x] = keep;
+    if (clk && threadIdx.x == 0) {                      // shader clock: s_memtime ticks per 100 MHz s_memrealtime tick (microarch guide, DVFS item 6)
+        clk[2 * blockIdx.x] = __builtin_amdgcn_s_memtime() - t0c;
+        clk[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime() - t0r;
+    }
 }
 template <int KIND>
 static void run(const char *name, unsigned *d) {
@@ -91,18 +121,25 @@ static void run(const char *name, unsigned *d) {
     const int iters = 20000;
     for (int wps : {1, 2, 3, 4}) {
         dim3 grid(256 * wps);
-        k<KIND><<<grid, 256>>>(d, 400, 3.0f, 0.25f);
+        static unsigned long long *clk = nullptr;
+        if (!clk) (void)hipMalloc(&clk, 2048 * 2 * sizeof(unsigned long long));
+        k<KIND><<<grid, 256>>>(d, 400, 3.0f, 0.25f, nullptr);
         (void)hipEventRecord(e0);
-        k<KIND><<<grid, 256>>>(d, iters, 3.0f, 0.25f);
+        k<KIND><<<grid, 256>>>(d, iters, 3.0f, 0.25f, clk);
         (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
         float ms; (void)hipEventElapsedTime(&ms, e0, e1);
-        printf("%-10s waves/SIMD %d: %6.1f ns per 16-pixel row per SIMD\n", name, wps, ms * 1e6 / iters / wps);
+        unsigned long long h[2];
+        (void)hipMemcpy(h, clk + 2 * 100, sizeof(h), hipMemcpyDeviceToHost);
+        const double ghz = (double)h[0] / (double)h[1] * 0.1;
+        printf("%-10s waves/SIMD %d: %6.1f ns = %6.1f cycles per 16-pixel row per SIMD (shader clock %.2f GHz)\n", name, wps, ms * 1e6 / iters / wps,
+               ms * 1e6 / iters / wps * ghz, ghz);
     }
 }
 int main() {
     unsigned *d; (void)hipMalloc(&d, 256 * 4 * 256 * 4);
     for (int rep = 0; rep < 2; ++rep) {
         run<0>("a16", d); run<1>("a16cvt", d); run<2>("a16pipe", d); run<3>("b32", d); run<4>("b32cvt", d);
+        run<5>("chain", d); run<6>("epi13", d); run<7>("a16indep", d);
     }
     return 0;
 }
