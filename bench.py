@@ -184,7 +184,13 @@ def main():
                        acc_bits=b.pe_acc_bits, add_bits=b.pe_add_bits, name=b.name) for b in bundles]
         thr = min(os.cpu_count() or 1, 16)
         x0 = pool[0][0:1]
-        got = forward_chain(pool[0], 0, torch.cuda.current_stream(dev))[0:1].cpu().numpy()
+        if graphs:      # --graph: what is timed is the replay, so the replay's own output buffer is what is compared
+            with torch.cuda.stream(streams[0]):
+                gq, _ = graphs[(0, 0)].replay()
+            torch.cuda.synchronize()
+            got = gq[0:1].cpu().numpy()
+        else:
+            got = forward_chain(pool[0], 0, torch.cuda.current_stream(dev))[0:1].cpu().numpy()
         torch.cuda.synchronize()
         xs = x0.cpu().numpy()
         CO.forward(onets[0], xs[:, :, :64, :64], threads=thr, want_f=False)       # warm the thread pool
@@ -204,7 +210,9 @@ def main():
                   "psnr_db": "inf" if maxdiff == 0 else float(10 * np.log10(255.0 ** 2 / np.mean(diff.astype(np.float64) ** 2)))}
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
-            cpu = {"value": round(1.0 / dt, 4), "unit": "frames/s", "cores": thr, "kind": "port",
+            cpu = {"reference_sim_py": {"value": 0.106, "unit": "frames/s", "cores": 8, "workload": "SESR-x4 1x1x1080x1920 through the reference's own "
+                                        "sim.py path, dump flags off", "where": "survey container (SURVEY.md 6): the reference cannot travel to the GPU box, not re-run here"},
+                   "value": round(1.0 / dt, 4), "unit": "frames/s", "cores": thr, "kind": "port",
                    "sample": f"1 frame {H}x{W} of the same workload through oracle/sesrq_oracle.c (OpenMP, {thr} threads), {dt:.2f} s "
                              "(the same run is the parity reference)"}
 
@@ -241,17 +249,29 @@ def main():
         ach = alg[kdom] / (launch_ms[kdom] * 1e-3)
         per_frame_fused = sum(alg) / max(B, 1)
         per_frame_layerwise = layerwise_bytes_per_px(bundle, True) * H * W
+        hh, ww = H * bundle.pixel_shuffle, W * bundle.pixel_shuffle
+        for ej, bj in zip(engines[1:], bundles[1:]):        # chained nets: the downstream nets' bytes too (int8 hand-off in)
+            per_frame_fused += sum(launch_bytes_per_px(bj, f, c, False) for f, c in ej.launch_plan()) * hh * ww
+            per_frame_layerwise += layerwise_bytes_per_px(bj, False) * hh * ww
+            hh, ww = hh * bj.pixel_shuffle, ww * bj.pixel_shuffle
         # HBM bytes per launch / VALU + MFMA utilisation of that kernel from the committed rocprofv3 PMC passes (profiles/):
         # FETCH_SIZE and WRITE_SIZE in separate runs, FETCH_SIZE doubled for 16-B/lane streaming reads (MI355X_MICROARCH.md, HBM)
         prof = {}
         pfile = os.path.join(ROOT, "profiles", "pmc_summary.json")
         if os.path.isfile(pfile):
             prof = json.load(open(pfile)).get(args.workload, {}).get(f"launch{kdom}:{names[plan[kdom][0]]}", {})
+        # counters cannot be collected inside this run (rocprofv3 PMC passes are separate processes): what the committed profile of the
+        # SAME kernel holds is reported under an explicit provenance key, never as if it had been measured here
+        committed = None
+        if prof:
+            committed = {"source": "profiles/pmc_summary.json (builder's box, tools/profile_round.sh, 1 stream, one rocprofv3 --pmc pass per "
+                                   "counter group)", "hbm_bytes_per_launch": prof.get("hbm_bytes_per_launch"),
+                         "issue": {"valu_util": prof.get("valu_util"), "mfma_util": prof.get("mfma_util"),
+                                   "wait_inst_frac": prof.get("wait_inst_frac"), "lds_util": prof.get("lds_util")}}
         roofline = {"bound": "hbm", "achieved": round(ach / 1e9, 2), "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                    "frac": round(ach / HBM_PEAK, 4), "traffic": prof.get("hbm_bytes_per_launch"),
+                    "frac": round(ach / HBM_PEAK, 4), "traffic": prof.get("hbm_bytes_per_launch"), "from_committed_profile": committed,
                     "kernel": f"launch{kdom}:layers{plan[kdom][0]}-{plan[kdom][0] + plan[kdom][1] - 1}:{names[plan[kdom][0]]}",
                     "kernel_ms": round(launch_ms[kdom], 5), "algorithmic_bytes_per_launch": alg[kdom],
-                    "valu_util": prof.get("valu_util"), "mfma_util": prof.get("mfma_util"),
                     "launches": [{"layers": [f, f + c - 1], "kernel": names[f], "ms": round(launch_ms[j], 5), "alg_bytes": alg[j],
                                   "frac": round(alg[j] / (launch_ms[j] * 1e-3) / HBM_PEAK, 4)} for j, (f, c) in enumerate(plan)],
                     "forward_device_ms": round(fwd_ms, 5),
@@ -267,6 +287,7 @@ def main():
         e2e = None
         if world == 1 and not args.no_e2e and B > 0:
             e2e = e2e_leg(torch, engines, pool, outs, B)
+            e2e["int8_frames"] = e2e_leg(torch, engines, pool, outs, B, int8_in=True)
 
         result = {"metric": "INT8 SESR frames/sec (whole job) + PSNR-vs-ref-sim (bit-exact)", "value": round(fps, 2),
                   "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -288,17 +309,23 @@ def main():
         print(json.dumps(result), flush=True)
 
 
-def e2e_leg(torch, engines, pool, outs, B, frames=96, depth=3):
+def e2e_leg(torch, engines, pool, outs, B, frames=96, depth=3, int8_in=False):
     """Host -> device -> host for `frames` steps: pinned host buffers, H2D on one stream, the kernels on a second, D2H on a
     third, `depth` frames in flight; PCIe-bound by construction (SURVEY 8e asks for it to be reported separately).  The first
     DMA out of / into a freshly pinned buffer is slow (6 vs 56 GB/s measured here), so every buffer is cycled twice before
-    the clock starts."""
+    the clock starts.  int8_in: the frames cross PCIe already quantised (q0 = clamp8(rint(x / s0 + z0)) formed on the host -- what
+    a camera pipeline with uint8 frames hands over): a quarter of the input bytes, the engine's int8 entry (SESRQ_I8)."""
     dev = pool[0].device
-    hin = [pool[i % len(pool)].cpu().pin_memory() for i in range(depth)]
+    if int8_in:
+        b0 = engines[0].bundle
+        s0, z0 = float(__import__("numpy").float32(b0.scale[0])), float(b0.zero[0])
+        hin = [torch.clamp(torch.round(pool[i % len(pool)].cpu() / s0 + z0), -128, 127).to(torch.int8).pin_memory() for i in range(depth)]
+    else:
+        hin = [pool[i % len(pool)].cpu().pin_memory() for i in range(depth)]
     shapes = [o.shape for o in outs[0]]
     douts = [[torch.empty(s, dtype=torch.int8, device=dev) for s in shapes] for _ in range(depth)]
     hout = [torch.empty(shapes[-1], dtype=torch.int8).pin_memory() for _ in range(depth)]
-    din = [torch.empty_like(pool[0]) for _ in range(depth)]
+    din = [torch.empty(pool[0].shape, dtype=hin[0].dtype, device=dev) for _ in range(depth)]
     s_in, s_k, s_out = (torch.cuda.Stream(device=dev) for _ in range(3))
     ev_in = [torch.cuda.Event() for _ in range(depth)]
     ev_k = [torch.cuda.Event() for _ in range(depth)]
@@ -328,9 +355,9 @@ def e2e_leg(torch, engines, pool, outs, B, frames=96, depth=3):
     t0 = time.perf_counter()
     run(frames)
     dt = time.perf_counter() - t0
-    mb_in = pool[0].numel() * 4 / 1e6
+    mb_in = hin[0].numel() * hin[0].element_size() / 1e6
     mb_out = hout[0].numel() / 1e6
-    return {"value": round(frames * B / dt, 2), "unit": "frames/s", "bound": "pcie",
+    return {"value": round(frames * B / dt, 2), "unit": "frames/s", "bound": "pcie", "input_dtype": "i8" if int8_in else "f32",
             "h2d_MB_per_step": round(mb_in, 2), "d2h_MB_per_step": round(mb_out, 2),
             "pcie_GBps": round((mb_in + mb_out) * frames / dt / 1e3, 2),
             "note": f"pinned host buffers, H2D / kernels / D2H on three streams, {depth} frames in flight, {frames} steps; never `value`"}

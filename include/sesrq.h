@@ -131,7 +131,12 @@ int sesrq_forward(const sesrq_net *net, const void *in, int in_dtype, void *out_
  * may be NULL):
  *   act[k]    : (N, C_k, H, W) int8   input.k.pt, k = 0..L-1      (INPUT_W_FLG)
  *   pe_out[k] : (N, 4, OC_k, H, W) int32 pe_outputK_P.pt           (OUTPUT_PE_W_FLG)
- *   pe_add[k] : (N, OC_k, H, W) int32 pe_add_outputK.pt            (OUTPUT_PE_ADD_W_FLG) */
+ *   pe_add[k] : (N, OC_k, H, W) int32 pe_add_outputK.pt            (OUTPUT_PE_ADD_W_FLG)
+ * A layer with taps runs its per-PE (general) kernel: on the MFMA engine the PE taps are written by the MFMA kernels
+ * themselves; act[0] (the quantised input), the overflow counters and the pe-split last layer (OC <= 4) take their layer
+ * to the dot4 kernels, which carry those taps.  The fused launches (trio, fused front) never run in a debug forward.
+ * There is no sesrq_forward_cpu (SURVEY 8b proposed one): the CPU restatement of the arithmetic is test infrastructure
+ * and lives under oracle/, outside the product library. */
 typedef struct sesrq_taps {
     void *act[SESRQ_MAX_LAYERS];
     void *pe_out[SESRQ_MAX_LAYERS];

@@ -252,7 +252,8 @@ int sesrq_create(const sesrq_net_desc *d, const sesrq_options *opts, sesrq_net *
     net->fuse_hidden = o.fuse_hidden;
     if (o.wg_budget < 0) { set_error("sesrq_create: wg_budget must be >= 0"); delete net; return 1; }
     net->wg_budget = o.wg_budget;
-    if (!(o.i8_in_scale >= 0.f) || o.i8_in_zero < -32768 || o.i8_in_zero > 127) { set_error("sesrq_create: bad int8 input domain"); delete net; return 1; }
+    // the int8 hand-off domain is an upstream net's OUTPUT domain (scale_L, zero[L]): an int8-range zero point
+    if (!(o.i8_in_scale >= 0.f) || o.i8_in_zero < -128 || o.i8_in_zero > 127) { set_error("sesrq_create: bad int8 input domain (zero point must be in [-128, 127])"); delete net; return 1; }
     net->i8_in_scale = o.i8_in_scale;
     net->i8_in_zero = o.i8_in_zero;
     if (o.anchor_add && d->layers[0].ic * d->pixel_shuffle * d->pixel_shuffle != d->layers[L - 1].oc) {
@@ -451,10 +452,11 @@ static int forward_impl(const sesrq_net *net, const void *in, int in_dtype, void
     void *bufRC = net->rc_separate ? (void *)(ws + wl.off_rc) : bufS;
     const void *cur = in;
     int launch = 0;
+    const int NL = taps ? L : sesrq_launch_plan(net, nullptr, nullptr);       // launches this forward may issue (ev[] holds 2 per launch)
     struct ClearKernelEvents { ~ClearKernelEvents() { tl_kernel_events = KernelEvents{}; } } clear_on_any_exit;
     for (int k = 0; k < L; ++launch) {
         const LayerPlan &lp = net->layers[k];
-        if (k == 0 && quad_active(net, taps) && !(net->anchor_add && in_dtype != SESRQ_F32)) {
+        if (k == 0 && quad_active(net, taps)) {
             // ---- fused front: layers 0..3 in one launch (sesrq_quad.hip)
             QuadArgs q;
             memset(&q, 0, sizeof(q));
@@ -484,6 +486,7 @@ static int forward_impl(const sesrq_net *net, const void *in, int in_dtype, void
             q.s_prev = net->i8_in_scale; q.z_prev = (float)net->i8_in_zero;
             q.fd = net->fd;
             const int src = in_dtype == SESRQ_F32 ? SRC_F32 : (net->i8_in_scale > 0.f ? SRC_I8D : SRC_I8);
+            if (launch >= NL) { set_error("sesrq_forward: more launches than sesrq_launch_plan reports"); return 1; }
             if (ev) tl_kernel_events = KernelEvents{ev[2 * launch], ev[2 * launch + 1]};     // begin / end events of the next kernel
             if (launch_quad(q, lp.general, src, st)) return 1;
             tl_kernel_events = KernelEvents{};
@@ -508,6 +511,7 @@ static int forward_impl(const sesrq_net *net, const void *in, int in_dtype, void
                 t.l[j].zlo = lj.base.relu ? fmaxf(lj.base.z_next, -128.f) : -128.f;
                 t.l[j].pad_next = net->layers[k + j + 1].base.pad_word;
             }
+            if (launch >= NL) { set_error("sesrq_forward: more launches than sesrq_launch_plan reports"); return 1; }
             if (ev) tl_kernel_events = KernelEvents{ev[2 * launch], ev[2 * launch + 1]};     // begin / end events of the next kernel
             if (launch_trio(t, (k + 2 == L - 2) ? EPI_PRERES : EPI_MID, st)) return 1;
             tl_kernel_events = KernelEvents{};
@@ -517,6 +521,12 @@ static int forward_impl(const sesrq_net *net, const void *in, int in_dtype, void
         }
         ConvArgs a = lp.base;
         const bool dbg = taps && (taps->pe_out[k] || taps->pe_add[k] || taps->overflow);
+        // the quantised input of layer 0 (input.0.pt) is a tap of the dot4 kernel: with it layer 0 runs there
+        const bool q0tap = taps && k == 0 && taps->act[0];
+        // PE taps on the MFMA engine: the per-PE kernels write them themselves (GEN_TAP); the overflow counters, the quantised
+        // input tap and the pe-split last layer (OC <= 4) stay with the dot4 kernels
+        const bool mfma_ok = net->engine != SESRQ_ENGINE_DOT4 && lp.mfma_kind != MFMA_NONE && (k > 0 || net->fd.ok);
+        const bool tap_mfma = dbg && !taps->overflow && !q0tap && mfma_ok && !lp.d_afrag_pesplit;
         LayerPlan eff = lp;
         eff.general = lp.general || net->force_general || dbg;
         a.wpk = eff.general ? lp.d_wpk_general : lp.d_wpk_merged;
@@ -533,8 +543,6 @@ static int forward_impl(const sesrq_net *net, const void *in, int in_dtype, void
         a.rc_in = bufRC;
         a.out_q = out_q; a.out_f = (float *)out_f;
         a.anchor = (net->anchor_add && in_dtype == SESRQ_F32) ? (const float *)in : nullptr;
-        // the quantised input of layer 0 (input.0.pt) is a tap of the dot4 kernel: any debug tap on layer 0 runs it there
-        const bool q0tap = taps && k == 0 && taps->act[0];
         if (taps) {
             a.dbg_pe = (int *)taps->pe_out[k];
             a.dbg_add = (int *)taps->pe_add[k];
@@ -544,15 +552,16 @@ static int forward_impl(const sesrq_net *net, const void *in, int in_dtype, void
                 set_error("sesrq_forward: debug unpack launch failed"); return 1;
             }
         }
+        if (launch >= NL) { set_error("sesrq_forward: more launches than sesrq_launch_plan reports"); return 1; }
         if (ev) tl_kernel_events = KernelEvents{ev[2 * launch], ev[2 * launch + 1]};     // begin / end events of the next kernel
-        const bool use_mfma = net->engine != SESRQ_ENGINE_DOT4 && lp.mfma_kind != MFMA_NONE && !dbg && !q0tap && (k > 0 || net->fd.ok);
+        const bool use_mfma = mfma_ok && (!dbg || tap_mfma) && !q0tap;
         if (use_mfma) {
             a.afrag = eff.general ? lp.d_afrag_general : lp.d_afrag_merged;
             // exactly one PE can saturate (and nothing forces the full per-PE path): merged chain + that PE's chain
             const bool one_pe = lp.general && !net->force_general && !dbg && lp.d_afrag_others && net->acc_bits == 18 && net->add_bits == 20;
             if (one_pe) { a.afrag = lp.d_afrag_others; a.afrag2 = lp.d_afrag_general; a.risky_pe = __builtin_ctz(lp.risky_mask); }
             if (lp.d_afrag_pesplit) a.afrag = lp.d_afrag_pesplit;
-            if (launch_mfma(lp, a, src, epi, eff.general, st, one_pe)) return 1;
+            if (launch_mfma(lp, a, src, epi, eff.general, st, one_pe, tap_mfma)) return 1;
         } else if (launch_dot4(eff, a, src, epi, st)) return 1;
         tl_kernel_events = KernelEvents{};
         cur = dst;
@@ -575,9 +584,10 @@ int sesrq_forward_timed(const sesrq_net *net, const void *in, int in_dtype, void
                         void *workspace, size_t workspace_bytes, void *stream, int iters, float *launch_ms, float *forward_ms) {
     if (!net || iters < 1 || !launch_ms) { set_error("sesrq_forward_timed: bad argument"); return 1; }
     const int NL = sesrq_launch_plan(net, nullptr, nullptr);
-    std::vector<hipEvent_t> ev((size_t)2 * NL * iters);
-    for (auto &e : ev) HIP_OK(hipEventCreate(&e));
+    std::vector<hipEvent_t> ev((size_t)2 * NL * iters, nullptr);
     int rc = 0;
+    for (auto &e : ev)
+        if (hipEventCreate(&e) != hipSuccess) { set_error("sesrq_forward_timed: hipEventCreate failed"); e = nullptr; rc = 1; break; }
     for (int it = 0; it < iters && !rc; ++it)
         rc = forward_impl(net, in, in_dtype, out_q, out_f, N, H, W, workspace, workspace_bytes, stream, nullptr,
                           ev.data() + (size_t)2 * NL * it);
@@ -598,7 +608,8 @@ int sesrq_forward_timed(const sesrq_net *net, const void *in, int in_dtype, void
         }
         if (forward_ms) *forward_ms = (float)(fw / iters);
     }
-    for (auto &e : ev) (void)hipEventDestroy(e);
+    for (auto &e : ev)
+        if (e) (void)hipEventDestroy(e);
     return rc;
 }
 

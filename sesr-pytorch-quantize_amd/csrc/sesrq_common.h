@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include <string>
 #include <vector>
 
@@ -19,6 +20,25 @@ template <typename K, typename A>
 inline void launch_kernel(K kern, dim3 grid, dim3 block, unsigned lds, hipStream_t st, const A &a) {
     if (tl_kernel_events.start) hipExtLaunchKernelGGL(kern, grid, block, lds, st, tl_kernel_events.start, tl_kernel_events.stop, 0, a);
     else hipLaunchKernelGGL(kern, grid, block, lds, st, a);
+}
+
+// Compute units of the CURRENT device, cached per device id (a process may hold nets on several devices: net->device).
+inline int device_cu_count() {
+    static int cus[64] = {0};                       // benign race: every writer stores the same value
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+    if (!cus[dev]) {
+        hipDeviceProp_t prop;
+        cus[dev] = (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+    }
+    return cus[dev];
+}
+// Integer tuning knob from the environment, read ONCE per process (first use), clamped to [lo, hi]; absent / out of range = dflt.
+inline int env_knob(const char *name, int dflt, int lo, int hi) {
+    const char *e = getenv(name);
+    if (!e) return dflt;
+    const int v = atoi(e);
+    return (v < lo || v > hi) ? dflt : v;
 }
 
 enum Epi { EPI_MID = 0, EPI_PRERES = 1, EPI_LAST = 2 };
@@ -188,7 +208,7 @@ void set_error(const std::string &msg);
 // dot4 engine
 int launch_dot4(const LayerPlan &lp, const ConvArgs &a, int src, int epi, hipStream_t st);
 // mfma engine
-int launch_mfma(const LayerPlan &lp, const ConvArgs &a, int src, int epi, bool general, hipStream_t st, bool one_risky_pe = false);
+int launch_mfma(const LayerPlan &lp, const ConvArgs &a, int src, int epi, bool general, hipStream_t st, bool one_risky_pe = false, bool tap = false);
 int launch_trio(const TrioArgs &a, int epi_c, hipStream_t st);
 int launch_quad(const QuadArgs &a, bool hybrid, int src, hipStream_t st);
 int launch_unpack_nhwc16(const void *nhwc, signed char *nchw, int N, int C, int H, int W, hipStream_t st);

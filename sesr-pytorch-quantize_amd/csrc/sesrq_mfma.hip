@@ -284,7 +284,7 @@ struct StageNHWC16 {
 // ------------------------------------------------------------------ hidden 3x3, 16 -> 16 channels
 template <int MODE, int EPI>
 __global__ __launch_bounds__(256) void mfma_h3_kernel(const ConvArgs a) {
-    constexpr bool GENERAL = MODE == GEN_STD || MODE == GEN_ANY;
+    constexpr bool GENERAL = mode_general(MODE);
     constexpr int SW = MTW + 4;                      // 1 left halo + 64 + 1 right halo + over-read
     constexpr int SH = MTH + 2 + (MODE != MERGED ? 1 : 0);  // per-PE chains read row y+3 with zero weights
     constexpr int PW = GENERAL ? SW : 0;             // planar image: row pitch 4*68 = 272 dwords = 16 mod 64 banks
@@ -292,7 +292,7 @@ __global__ __launch_bounds__(256) void mfma_h3_kernel(const ConvArgs a) {
     const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, n = l & 15, g = l >> 4;
     const int x0 = blockIdx.x * MTW, n_img = blockIdx.z;
     const int4 *fr = a.afrag;
-    constexpr bool BIASED = MODE != GEN_ANY;     // requant without v_cvt: sums carry + MAGIC_I (needs |s| < 2^22)
+    constexpr bool BIASED = mode_biased(MODE);     // requant without v_cvt: sums carry + MAGIC_I (needs |s| < 2^22)
     int4 ac = fr[g];
     if constexpr (BIASED) { ac.x += MAGIC_I; ac.y += MAGIC_I; ac.z += MAGIC_I; ac.w += MAGIC_I; }
     v4i A[GENERAL ? 4 : 3];
@@ -347,6 +347,7 @@ __global__ __launch_bounds__(256) void mfma_h3_kernel(const ConvArgs a) {
                         const v4i b = {q[0], q[1], q[2], q[3]};
                         acc[p] = mfma(A[p], b, zero);
                     }
+                    if constexpr (MODE == GEN_TAP) tap_sums<4>(acc, a, n_img, y0 + y4 + r, gx, g, 0);
                     finish_sums<MODE>(s4[r], acc, ac, a);
                 }
                 emit_rows4<EPI, false, BIASED>(s4, a, io, y4, zlo);
@@ -370,7 +371,7 @@ __global__ __launch_bounds__(256) void mfma_h3_kernel(const ConvArgs a) {
 // NV (EPI_LAST only): real accumulator rows per lane group, 3 for up to 12 output channels (last_slot_oc, sesrq_common.h)
 template <int MODE, int EPI, int FAST = 0, int NV = 4>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SESRQ_H5_WAVES))) void mfma_h5_kernel(const ConvArgs a) {
-    constexpr bool GENERAL = MODE == GEN_STD || MODE == GEN_ANY;
+    constexpr bool GENERAL = mode_general(MODE);
     constexpr int SW = MTW + 8;          // 2 + 64 + 2 halo, + over-read of the kx = 4..7 group
     constexpr int SH = MTH + 4;
     // per-PE (general) kernels: column-major PE-planar image [col][PE][row] (StageNHWC16, CP > 0): plane pitch CP = 13 dwords,
@@ -387,7 +388,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SESRQ_H5_WA
     const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, n = l & 15, g = l >> 4;
     const int x0 = blockIdx.x * MTW, n_img = blockIdx.z;
     const int4 *fr = a.afrag;
-    constexpr bool BIASED = MODE != GEN_ANY;     // requant without v_cvt: sums carry + MAGIC_I (needs |s| < 2^22)
+    constexpr bool BIASED = mode_biased(MODE);     // requant without v_cvt: sums carry + MAGIC_I (needs |s| < 2^22)
     int4 ac = fr[g];
     if constexpr (BIASED) { ac.x += MAGIC_I; ac.y += MAGIC_I; ac.z += MAGIC_I; ac.w += MAGIC_I; }
     const float zlo = a.relu ? fmaxf(EPI == EPI_LAST ? a.z_out : a.z_next, -128.f) : -128.f;
@@ -489,6 +490,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SESRQ_H5_WA
                         acc[p] = mfma(A[p], b0, zero);
                         acc[p] = mfma(A[4 + p], b1, acc[p]);
                     }
+                    if constexpr (MODE == GEN_TAP) tap_sums<NV>(acc, a, n_img, y0 + y, gx, g, EPI == EPI_LAST ? NV : 0);
                     finish_sums<MODE, NV>(s4[r], acc, ac, a);
                     if constexpr (EPI == EPI_LAST) {
                         // a row below the frame is dropped by its offsets (FAST: the scalar one, else the lanes'), not by a
@@ -520,7 +522,7 @@ __global__ __launch_bounds__(256) void mfma_h5p_kernel(const ConvArgs a) {
     const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, n = l & 15, g = l >> 4;
     const int x0 = blockIdx.x * MTW, n_img = blockIdx.z;
     const int4 *fr = a.afrag;
-    constexpr bool BIASED = MODE != GEN_ANY;
+    constexpr bool BIASED = mode_biased(MODE);
     int4 ac = fr[0];
     if constexpr (BIASED) { ac.x += MAGIC_I; ac.y += MAGIC_I; ac.z += MAGIC_I; ac.w += MAGIC_I; }
     const float zlo = a.relu ? fmaxf(a.z_out, -128.f) : -128.f;
@@ -676,12 +678,12 @@ constexpr int F5_PITCH = F5_SH + 2;     // LDS column pitch in dwords (>= rows, 
 static_assert(F5_PITCH % 4 == 2 && 3 * F5_PITCH + F5_SH < 256, "column pitch: bank rule / ds_read2_b32 offset range");
 template <int MODE, int SRC, bool RC, int NCH>
 __device__ __forceinline__ void mfma_f5_body(const ConvArgs &a, int4 *buf0, int4 *buf1) {
-    constexpr bool GENERAL = MODE == GEN_STD || MODE == GEN_ANY;
+    constexpr bool GENERAL = mode_general(MODE);
     constexpr int SH = F5_SH, SWP = F5_SWP, PITCH = F5_PITCH;
     const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, n = l & 15, g = l >> 4;
     const int x0 = blockIdx.x * MTW, n_img = blockIdx.z;
     const int4 *fr = a.afrag;
-    constexpr bool BIASED = MODE != GEN_ANY;     // requant without v_cvt: sums carry + MAGIC_I (needs |s| < 2^22)
+    constexpr bool BIASED = mode_biased(MODE);     // requant without v_cvt: sums carry + MAGIC_I (needs |s| < 2^22)
     int4 ac = fr[g];
     if constexpr (BIASED) { ac.x += MAGIC_I; ac.y += MAGIC_I; ac.z += MAGIC_I; ac.w += MAGIC_I; }
     constexpr int NPE = GENERAL ? 4 : 1;
@@ -735,6 +737,7 @@ __device__ __forceinline__ void mfma_f5_body(const ConvArgs &a, int4 *buf0, int4
                         acc[p] = mfma(A[0][p], B0, zero);
                         acc[p] = mfma(A[1][p], B1, acc[p]);
                     }
+                    if constexpr (MODE == GEN_TAP) tap_sums<4>(acc, a, n_img, y0 + y4 + r, gx, g, 0);
                     finish_sums<MODE>(s4[r], acc, ac, a);
                 } else {
                     const v4i acc0 = {ac.x, ac.y, ac.z, ac.w};
@@ -796,16 +799,10 @@ template <typename K>
 static void launch(K kern, ConvArgs a, hipStream_t st, int tile_h = MTH) {
     static std::mutex mu;
     static std::map<const void *, int> occ;          // per kernel (all instantiations share this function type)
-    static int num_cu = 0;
+    const int num_cu = device_cu_count();
     int blocks_per_cu;
     {
         std::lock_guard<std::mutex> lk(mu);
-        if (!num_cu) {
-            int dev = 0;
-            hipDeviceProp_t prop;
-            if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) num_cu = prop.multiProcessorCount;
-            if (num_cu < 1) num_cu = 256;
-        }
         auto it = occ.find((const void *)kern);
         if (it == occ.end()) {
             int b = 0;
@@ -830,7 +827,7 @@ static void launch(K kern, ConvArgs a, hipStream_t st, int tile_h = MTH) {
         else launch(KERN<GEN_ANY, __VA_ARGS__>, a, st);                                  \
     } while (0)
 
-int launch_mfma(const LayerPlan &lp, const ConvArgs &a_in, int src, int epi, bool general, hipStream_t st, bool one_risky_pe) {
+int launch_mfma(const LayerPlan &lp, const ConvArgs &a_in, int src, int epi, bool general, hipStream_t st, bool one_risky_pe, bool tap) {
     ConvArgs a = a_in;
 #ifdef SESRQ_STAMPS
     if (!g_stampbuf) { (void)hipMalloc((void **)&g_stampbuf, 1 << 22); (void)hipMemset(g_stampbuf, 0, 1 << 22); }
@@ -838,7 +835,32 @@ int launch_mfma(const LayerPlan &lp, const ConvArgs &a_in, int src, int epi, boo
 #endif
     if ((size_t)a.H * a.W * 16 >= ((size_t)1 << 28)) { set_error("mfma: frame too large for 32-bit buffer offsets (H*W must stay below 2^24 pixels)"); return 1; }
     const bool std_bits = a.acc_lo == -131072 && a.acc_hi == 131071 && a.add_lo == -524288 && a.add_hi == 524287;
-    const int mode = !general ? MERGED : (std_bits ? (one_risky_pe ? HYB : GEN_STD) : GEN_ANY);
+    const int mode = tap ? GEN_TAP : (!general ? MERGED : (std_bits ? (one_risky_pe ? HYB : GEN_STD) : GEN_ANY));
+    if (mode == GEN_TAP) {      // debug forward with PE taps: the per-PE kernels in their run-time-bounds form, every output kind
+        if (lp.d_afrag_pesplit && a.afrag == lp.d_afrag_pesplit) { set_error("mfma: the pe-split last-layer kernel has no PE taps"); return 1; }
+        switch (lp.mfma_kind) {
+            case MFMA_H3:
+                if (epi == EPI_MID) launch(mfma_h3_kernel<GEN_TAP, EPI_MID>, a, st);
+                else if (epi == EPI_PRERES) launch(mfma_h3_kernel<GEN_TAP, EPI_PRERES>, a, st);
+                else { set_error("mfma: 3x3 last layer not supported"); return 1; }
+                break;
+            case MFMA_H5:
+                if (epi == EPI_MID) launch(mfma_h5_kernel<GEN_TAP, EPI_MID>, a, st);
+                else if (epi == EPI_PRERES) launch(mfma_h5_kernel<GEN_TAP, EPI_PRERES>, a, st);
+                else if (last_nv(a.oc) == 3) launch(mfma_h5_kernel<GEN_TAP, EPI_LAST, 0, 3>, a, st);
+                else launch(mfma_h5_kernel<GEN_TAP, EPI_LAST>, a, st);
+                break;
+            case MFMA_F5:
+                if (src == SRC_F32) { if (a.rc_out) launch(mfma_f5_kernel<GEN_TAP, SRC_F32, true, 4>, a, st, F5_TH); else launch(mfma_f5_kernel<GEN_TAP, SRC_F32, false, 4>, a, st, F5_TH); }
+                else if (src == SRC_I8D) { if (a.rc_out) launch(mfma_f5_kernel<GEN_TAP, SRC_I8D, true, 4>, a, st, F5_TH); else launch(mfma_f5_kernel<GEN_TAP, SRC_I8D, false, 4>, a, st, F5_TH); }
+                else { if (a.rc_out) launch(mfma_f5_kernel<GEN_TAP, SRC_I8, true, 4>, a, st, F5_TH); else launch(mfma_f5_kernel<GEN_TAP, SRC_I8, false, 4>, a, st, F5_TH); }
+                break;
+            default: set_error("mfma: layer shape not supported by the MFMA engine"); return 1;
+        }
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) { set_error(std::string("mfma launch failed: ") + hipGetErrorString(e)); return 1; }
+        return 0;
+    }
     switch (lp.mfma_kind) {
         case MFMA_H3:
             if (epi == EPI_MID) SESRQ_BY_MODE(mfma_h3_kernel, EPI_MID);

@@ -16,7 +16,11 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 constexpr float MAGIC = 12582912.f;   // 1.5 * 2^23
 
 // accumulate modes
-enum { MERGED = 0, GEN_STD = 1, GEN_ANY = 2, HYB = 3 };   // GEN_STD: 18/20-bit clamps as literals; HYB: one risky PE
+enum { MERGED = 0, GEN_STD = 1, GEN_ANY = 2, HYB = 3, GEN_TAP = 4 };   // GEN_STD: 18/20-bit clamps as literals; HYB: one risky PE
+// GEN_TAP = GEN_ANY + the reference's PE dump taps (pe_outputK_P / pe_add_outputK, myQL/quan_func.py:372-378, 439-443) written by
+// the MFMA per-PE kernels themselves (sesrq_forward_debug): the debug forward, never the production one
+__host__ __device__ constexpr bool mode_general(int m) { return m == GEN_STD || m == GEN_ANY || m == GEN_TAP; }
+__host__ __device__ constexpr bool mode_biased(int m) { return m != GEN_ANY && m != GEN_TAP; }
 
 __device__ __forceinline__ v4i mfma(v4i a, v4i b, v4i c) { return __builtin_amdgcn_mfma_i32_16x16x64_i8(a, b, c, 0, 0, 0); }
 __device__ __forceinline__ float med3(float v, float lo, float hi) { return __builtin_amdgcn_fmed3f(v, lo, hi); }
@@ -46,27 +50,6 @@ __device__ __forceinline__ float quotient_in(float x, float s, const FastDiv &fd
 // integer bounds) -- no v_rndne / v_cvt_i32
 __device__ __forceinline__ unsigned quantize_in_bits(float x, float s, float z, const FastDiv &fd) {
     return __builtin_bit_cast(unsigned, __fadd_rn(med3(__fadd_rn(quotient_in(x, s, fd), z), -128.f, 127.f), 12582912.f));
-}
-
-// general path: the MFMA operand of PE P = word P of four staged pixels.  Two v_pk_mov_b32 build the
-// four consecutive operand registers (each moves one word out of two different source pairs) instead of
-// four v_mov_b32.  op_sel/op_sel_hi = [s,s]: D.lo = src0.{lo|hi}, D.hi = src1.{lo|hi} (checked on gfx950).
-typedef int v2i __attribute__((ext_vector_type(2)));
-template <int P>
-__device__ __forceinline__ v4i gather4(const int4 a, const int4 b, const int4 c, const int4 d) {
-    const int av[4] = {a.x, a.y, a.z, a.w}, bv[4] = {b.x, b.y, b.z, b.w}, cv[4] = {c.x, c.y, c.z, c.w}, dv[4] = {d.x, d.y, d.z, d.w};
-    constexpr int h = 2 * (P / 2);
-    const v2i pa = {av[h], av[h + 1]}, pb = {bv[h], bv[h + 1]}, pc = {cv[h], cv[h + 1]}, pd = {dv[h], dv[h + 1]};
-    v2i lo, hi;
-    if constexpr ((P & 1) == 0) {
-        asm("v_pk_mov_b32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,0]" : "=v"(lo) : "v"(pa), "v"(pb));
-        asm("v_pk_mov_b32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,0]" : "=v"(hi) : "v"(pc), "v"(pd));
-    } else {
-        asm("v_pk_mov_b32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[1,1]" : "=v"(lo) : "v"(pa), "v"(pb));
-        asm("v_pk_mov_b32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[1,1]" : "=v"(hi) : "v"(pc), "v"(pd));
-    }
-    const v4i r = {lo[0], lo[1], hi[0], hi[1]};
-    return r;
 }
 
 // A wave-uniform float pinned to a VGPR.  hipcc 7.2 (clang 22) un-packs a v_pk_fma_f32 that sits in the shadow of an MFMA into two
@@ -211,6 +194,29 @@ __device__ __forceinline__ void finish_sums(int s[4], const v4i *acc, const int4
     }
 }
 
+// Debug taps of the per-PE MFMA kernels (GEN_TAP): lane (n, g) holds the four PE sums of accumulator rows 4g + i of pixel (gy, gx).
+// pe_out = the PE sums after the accumulator clamp, pe_add = their sum after the adder clamp (before the add constant) -- what the
+// reference dumps as pe_outputK_P.pt / pe_add_outputK.pt (myQL/quan_func.py:370-378, 437-443); same layout as the dot4 taps.
+// lastnv: 0 = hidden / first layer (row 4g + i = channel g + 4i, PE-major), else the last layer's slot map (last_slot_oc).
+template <int NV>
+__device__ __forceinline__ void tap_sums(const v4i *acc, const ConvArgs &a, int n_img, int gy, int gx, int g, int lastnv) {
+    if (gy >= a.H || gx >= a.W) return;
+    const size_t HW = (size_t)a.H * a.W, px = (size_t)gy * a.W + gx;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int oc = lastnv ? last_slot_oc(lastnv, g, i, a.oc, a.ps) : g + 4 * i;
+        if (oc >= a.oc) continue;
+        int t = 0;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const int pe = clampi3(acc[p][i], a.acc_lo, a.acc_hi);
+            t += pe;
+            if (a.dbg_pe) a.dbg_pe[(((size_t)n_img * 4 + p) * a.oc + oc) * HW + px] = pe;
+        }
+        if (a.dbg_add) a.dbg_add[((size_t)n_img * a.oc + oc) * HW + px] = clampi3(t, a.add_lo, a.add_hi);
+    }
+}
+
 // 4x4 transpose between lane groups (16 lanes each) and registers; its own inverse.
 // in : w[r] in lane (n, g) = word g of row r        out: w[g'] in lane (n, r') = word g' of row r'
 __device__ __forceinline__ void transpose4(unsigned w[4]) {
@@ -244,7 +250,12 @@ __device__ __forceinline__ void store_rows4(__amdgpu_buffer_rsrc_t rs, const Row
     const v4u v = {w[0], w[1], w[2], w[3]};
     // aux 16 = sc1: the activation tensor is only read again by the NEXT kernel; measured against the default policy,
     // sc0|sc1 and nt on 1080p: sc1 -6 % on the first layer, -3..5 % on the hidden layers when frames overlap; nt +12 %
-    __builtin_amdgcn_raw_buffer_store_b128(v, rs, io.voff, y4 * io.row_bytes, 16);
+    // The row offset rides in the VECTOR offset, soffset = 0, on purpose: gfx950 needs one wait state between a dwordx4 store with
+    // an SGPR soffset and a VALU write of its data registers (tools/store_hazard_probe.hip: 2000 of 8.4 M stores carried the
+    // overwritten register at 0 wait states), LLVM's hazard recognizer assumes such a store needs none, and hipcc 7.2 did place a
+    // v_mov / v_pk_fma of the data registers directly behind these stores (round 2's "garbage in the first output word").  For
+    // soffset = 0 the compiler pads the two wait states itself.  One v_add per four rows.
+    __builtin_amdgcn_raw_buffer_store_b128(v, rs, io.voff + y4 * io.row_bytes, 0, 16);
 }
 
 // hidden-layer output of 4 rows: s4[r][i] -> requant -> transpose -> one 16-byte store per lane

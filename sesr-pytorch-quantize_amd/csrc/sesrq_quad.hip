@@ -340,20 +340,8 @@ __global__ __launch_bounds__(256) void mfma_quad_kernel(const QuadArgs a) {
 // Launch geometry as sesrq_trio.hip: LDS padded to exactly `occ` workgroups per CU, strips cut into runs of (almost) equal length.
 template <typename K>
 static void launch_quad_k(K kern, QuadArgs a, hipStream_t st) {
-    static std::mutex mu;
-    static int num_cu = 0, occ = 0;
-    {
-        std::lock_guard<std::mutex> lk(mu);
-        if (!num_cu) {
-            int dev = 0;
-            hipDeviceProp_t prop;
-            if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) num_cu = prop.multiProcessorCount;
-            if (num_cu < 1) num_cu = 256;
-            const char *e = getenv("SESRQ_QUAD_OCC");          // tuning knob (workgroups per CU)
-            occ = e ? atoi(e) : 4;
-            if (occ < 1 || occ > 4) occ = 4;
-        }
-    }
+    static const int occ = env_knob("SESRQ_QUAD_OCC", 4, 3, 4);      // tuning knob (workgroups per CU), read once
+    const int num_cu = device_cu_count();
     const int lds = std::max(QUAD_LDS_BYTES, (160 * 1024 / occ) & ~1023);
     const int strips = (a.t.W + TV - 1) / TV, steps = (a.t.H + TH - 1) / TH;
     long long k = (a.t.wg_budget > 0 ? (long long)a.t.wg_budget : (long long)occ * num_cu) / ((long long)strips * a.t.N);

@@ -241,31 +241,20 @@ __global__ __launch_bounds__(256) void mfma_trio_kernel(const TrioArgs a) {
 // Launch geometry: the chip is filled EVENLY.  A workgroup lives for tens of microseconds here, so a compute unit that holds
 // one workgroup more than its neighbours sets the kernel time while the others idle (measured: 864 workgroups on 1024 slots,
 // SQ busy 1.47 x the average wave lifetime).  The dynamic LDS size is padded so that exactly `occ` workgroups fit a CU, and a
-// strip is cut into floor(occ * CUs / (strips * N)) runs whose lengths differ by at most one step.  Device properties are
-// process-static: one process drives one device (the package's process-per-GPU model, sesrq/dist.py).
+// strip is cut into floor(occ * CUs / (strips * N)) runs whose lengths differ by at most one step.
 template <typename K>
 static void launch_trio_k(K kern, TrioArgs a, hipStream_t st) {
-    static std::mutex mu;
-    static int num_cu = 0, occ = 0;
-    {
-        std::lock_guard<std::mutex> lk(mu);
-        if (!num_cu) {
-            int dev = 0;
-            hipDeviceProp_t prop;
-            if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) num_cu = prop.multiProcessorCount;
-            if (num_cu < 1) num_cu = 256;
-            const char *e = getenv("SESRQ_TRIO_OCC");          // tuning knob (workgroups per CU): 3 or 4
-            occ = e ? atoi(e) : 4;
-            if (occ < 1 || occ > 5) occ = 4;
-        }
-    }
+    // tuning knobs, read once: workgroups per CU (3 or 4: the LDS sizes a plain launch accepts and the kernel's registers allow),
+    // rows per partition unit (4 / 8, 0 = by run length)
+    static const int occ = env_knob("SESRQ_TRIO_OCC", 4, 3, 4), unit_knob = env_knob("SESRQ_TRIO_UNIT", 0, 4, 8);
+    const int num_cu = device_cu_count();
     const int lds = std::max(TRIO_LDS_BYTES, (160 * 1024 / occ) & ~1023);      // exactly occ workgroups per 160 KiB
     const int strips = (a.W + TV - 1) / TV, steps = (a.H + TH - 1) / TH;
     long long k = (a.wg_budget > 0 ? (long long)a.wg_budget : (long long)occ * num_cu) / ((long long)strips * a.N);
     k = std::max(1LL, std::min<long long>(k, steps));                     // a run is at least one full step on average
     a.chunk_steps = (int)((steps + k - 1) / k);
     a.run_unit = (steps < 3 * k) ? TH / 2 : TH;                           // short runs (< 3 steps) are cut in half-step units
-    if (const char *e = getenv("SESRQ_TRIO_UNIT")) { if (atoi(e) == 4 || atoi(e) == 8) a.run_unit = atoi(e); }     // tuning knob
+    if (unit_knob == 4 || unit_knob == 8) a.run_unit = unit_knob;
     dim3 grid(strips, (int)k, a.N);
     launch_kernel(kern, grid, dim3(256), (unsigned)lds, st, a);
 }

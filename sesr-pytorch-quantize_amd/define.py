@@ -1,9 +1,12 @@
 """Configuration surface of the INT8 integer path -- same names and meanings as the reference's
 ``define.py`` (reference define.py:1-36), so that a ``sim.py``-shaped script keeps working.
 
-Differences by design: values are validated once (``check()``), and the seven dump switches only
-control *optional debug taps* of the device engine (sesrq_forward_debug) -- nothing is written to
-the working directory unless a caller asks for it.
+Differences by design: values are validated once (``check()``), and the dump switches route through
+the device engine's debug taps (sesrq_forward_debug): with a ``*_W_FLG`` on, every forward of the
+spliced model also leaves the tensors the reference would have written under ``./output_pt/`` in the
+parameter store under the reference's file names (sesrq/lowering.py:_dump_taps), and
+``STORE.save_output_pt(dir)`` -- ``sim.py --dump dir`` -- writes the tree.  Nothing is written to the
+working directory unless a caller asks for it.
 """
 
 # which network the entry script builds: 3 = nrdm_3 (3->3 ch), 5 = SESR x4 (1->1 ch, PixelShuffle 4),
@@ -22,7 +25,8 @@ PE_ADD_BIT = 20       # the 4-input adder tree saturates here
 REQUAN_BIT = 16       # requant multiplier M < 2**16
 REQUAN_N_MAX = 32     # requant shift n <= 32
 
-# debug taps (reference: "write this intermediate to output_pt/ / output_txt/")
+# debug taps (reference: "write this intermediate to output_pt/ / output_txt/"); read at every forward, so a script may
+# switch them after import (define.INPUT_W_FLG = True)
 w_flg_c = False
 WEIGHT_W_FLG = w_flg_c and True
 INPUT_W_FLG = w_flg_c and True

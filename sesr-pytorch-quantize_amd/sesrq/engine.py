@@ -241,11 +241,14 @@ class Engine:
                                                       ws.data_ptr(), ws.numel(), st, iters, launch_ms, C.byref(fwd)))
         return list(launch_ms), float(fwd.value)
 
-    def forward_debug(self, x: torch.Tensor, pe: bool = True, overflow: bool = False):
+    def forward_debug(self, x: torch.Tensor, pe: bool = True, overflow: bool = False, acts: bool = True):
         """Forward with the reference's dump taps (define.py *_W_FLG): returns a dict with
         q_out, y, input{k} (int8 NCHW), pe_out{k} (N,4,OC,H,W int32), pe_add{k} (N,OC,H,W int32) and, with
         overflow=True, `overflow` (L,2) int32: PE sums above / below the accumulator range before saturation --
-        the events the reference prints as max_overflow / min_overflow (quan_func.py:358-361)."""
+        the events the reference prints as max_overflow / min_overflow (quan_func.py:358-361).
+        On the MFMA engine the PE taps are written by the per-PE MFMA kernels themselves; the quantised-input tap
+        (input0), the overflow counters and the pe-split last layer (OC <= 4) run their layer on the dot4 kernels.
+        acts=False: no input{k} taps (layer 0 then stays on its MFMA kernel too)."""
         dt = self._check_in(x)
         with torch.cuda.device(self.device):
             x = x.contiguous()
@@ -257,8 +260,9 @@ class Engine:
             taps = _lib.Taps()
             for k, l in enumerate(self.bundle.layers):
                 oc, ic = l.wq.shape[0], l.wq.shape[1]
-                res[f"input{k}"] = torch.empty((N, ic, H, W), dtype=torch.int8, device=self.device)
-                taps.act[k] = res[f"input{k}"].data_ptr()
+                if acts:
+                    res[f"input{k}"] = torch.empty((N, ic, H, W), dtype=torch.int8, device=self.device)
+                    taps.act[k] = res[f"input{k}"].data_ptr()
                 if pe:
                     res[f"pe_out{k}"] = torch.empty((N, 4, oc, H, W), dtype=torch.int32, device=self.device)
                     res[f"pe_add{k}"] = torch.empty((N, oc, H, W), dtype=torch.int32, device=self.device)

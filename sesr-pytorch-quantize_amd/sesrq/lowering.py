@@ -203,4 +203,42 @@ class SesrqGraphModule(torch.fx.GraphModule):
         eid = getattr(eng, "_op_id", None) or torch_op.register_engine(eng)
         q, y = torch.ops.sesrq.forward(x.float() if x.dtype != torch.int8 else x, eid)     # the registered operator
         self.__dict__["last_q"] = q
+        self._dump_taps(eng, x)
         return y
+
+    def _dump_taps(self, eng, x):
+        """The reference's dump switches (define.py:23-31): with a *_W_FLG on, the forward also leaves the tensors the
+        reference would have written under ./output_pt/ in the parameter store, under the reference's file names
+        (myQL/quan_func.py:284, 378, 443, 489, 536-609) -- `STORE.save_output_pt(dir)` then writes the
+        tree.  They come from the device engine's debug forward (sesrq_forward_debug), not from a second code path."""
+        import define
+        flags = {n: bool(getattr(define, n, False)) for n in ("INPUT_W_FLG", "OUTPUT_PE_W_FLG", "OUTPUT_PE_ADD_W_FLG", "BIAS_W_FLG",
+                                                              "BIAS_QUAN_W_FLG", "REQUAN_FACTOR_W_FLG")}
+        if not any(flags.values()):
+            return
+        b = eng.bundle
+        L = b.L
+        if flags["INPUT_W_FLG"] or flags["OUTPUT_PE_W_FLG"] or flags["OUTPUT_PE_ADD_W_FLG"]:
+            res = eng.forward_debug(x.float() if x.dtype != torch.int8 else x,
+                                    pe=flags["OUTPUT_PE_W_FLG"] or flags["OUTPUT_PE_ADD_W_FLG"])
+            r = b.pixel_shuffle
+            for k in range(L):
+                if flags["INPUT_W_FLG"]:
+                    STORE[f"input/input.{k}"] = res[f"input{k}"].float().cpu()
+                if flags["OUTPUT_PE_W_FLG"]:
+                    for p in range(b.pe_num):
+                        STORE[f"pe_out/pe_output{k}_{p}"] = res[f"pe_out{k}"][0, p].float().cpu()
+                if flags["OUTPUT_PE_ADD_W_FLG"]:
+                    STORE[f"pe_add/pe_add_output{k}"] = res[f"pe_add{k}"].float().cpu()
+            if flags["INPUT_W_FLG"]:        # input.L.pt: the int8 result before PixelShuffle (quan_func.py:592)
+                qL = res["q_out"].float()
+                STORE[f"input/input.{L}"] = (torch.nn.functional.pixel_unshuffle(qL, r) if r > 1 else qL).cpu()
+        if flags["BIAS_QUAN_W_FLG"]:
+            for k, l in enumerate(b.layers):
+                STORE[f"bias/conv.bias.quan{k}"] = torch.from_numpy(np.asarray(l.add_const, dtype=np.float32)).reshape(1, -1, 1, 1)
+        if flags["REQUAN_FACTOR_W_FLG"]:
+            for k, l in enumerate(b.layers):    # the reference's names: layer k -> "k_k+1" (layer L-2 too, although it targets domain 1)
+                STORE[f"requan_factor/requan_{k}_{k + 1}"] = int(l.M)
+                STORE[f"requan_factor/n_{k}_{k + 1}"] = int(l.n)
+            STORE["requan_factor/requan_res"] = int(b.M_res)
+            STORE["requan_factor/n_res"] = int(b.n_res)

@@ -44,7 +44,7 @@ class ParamStore:
     def load_output_pt(self, root: str = "output_pt") -> int:
         import torch
         n = 0
-        for sub in ("input", "weight", "bias", "requan_factor", "residual"):
+        for sub in ("input", "weight", "bias", "requan_factor", "residual", "pe_out", "pe_add"):
             d = os.path.join(root, sub)
             if not os.path.isdir(d):
                 continue

@@ -123,8 +123,13 @@ def main(argv=None):
     ap.add_argument("--calib", help="output_pt directory written by the reference's test.py")
     ap.add_argument("--input", required=True, help="frame tensor: .pt (torch) or .npy, shape (N,C,H,W) float32")
     ap.add_argument("--save", help="write the float result here (.npy)")
+    ap.add_argument("--dump", help="write the parameter store as an output_pt-compatible tree here (what the define.py *_W_FLG "
+                                   "switches select, plus weights and activation domains); all dump switches are turned on")
     args = ap.parse_args(argv)
     define.check()
+    if args.dump:
+        for n in ("WEIGHT_W_FLG", "INPUT_W_FLG", "BIAS_W_FLG", "BIAS_QUAN_W_FLG", "OUTPUT_PE_W_FLG", "OUTPUT_PE_ADD_W_FLG", "REQUAN_FACTOR_W_FLG"):
+            setattr(define, n, True)
     if args.calib:
         STORE.load_output_pt(args.calib)
     model = splice(float_model(args.mflag, args.ckpt, args.params))
@@ -138,6 +143,9 @@ def main(argv=None):
     print("output:", tuple(gfake.shape), "engines:", model._sesrq_engine(gfake.device).layer_engines())
     if args.save:
         np.save(args.save, gfake.cpu().numpy())
+    if args.dump:
+        STORE.save_output_pt(args.dump)
+        print("dumped:", args.dump)
     return gfake
 
 

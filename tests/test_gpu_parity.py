@@ -56,7 +56,8 @@ def test_golden_stage_by_stage(path, eng):
     fx, meta, net, x = fixture_case(path)
     e = make_engine(net, eng)
     xt = torch.from_numpy(x).to(_dev())
-    use_pe = eng[0] == "dot4"        # the PE dump taps are a dot4-engine feature; with them a layer runs on dot4
+    # the PE dump taps: dot4 kernels on the dot4 engine, the per-PE MFMA kernels themselves (GEN_TAP) on the MFMA engine
+    use_pe = eng[0] in ("dot4", "mfma")
     res = e.forward_debug(xt, pe=use_pe)
     if eng[0] != "dot4":
         assert all(s.startswith("mfma") for s in e.layer_engines()), e.layer_engines()
@@ -86,6 +87,10 @@ def test_golden_stage_by_stage(path, eng):
     for name in fx.files:
         if name in got and name not in ("x",):
             _cmp(name, got[name], fx[name])
+    if eng[0] == "mfma":     # without the input taps layer 0 keeps its MFMA kernel too: its PE taps must be the same bytes
+        res2 = e.forward_debug(xt, pe=True, acts=False)
+        for nm in ("pe_out0", "pe_add0", "pe_out4", "pe_add4", "q_out"):
+            assert torch.equal(res2[nm], res[nm]), nm
     # production call (no taps; this is where the fused hidden trio runs) must give the same result
     q, y = e.forward(xt)
     _cmp("q_out(production)", q, got["q_out"])

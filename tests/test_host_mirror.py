@@ -124,6 +124,69 @@ def test_spliced_model_forward_is_the_golden_output(case):
     assert model.last_q.dtype == torch.int8
 
 
+SIM_INPUT = {5: "rand_SR_Input_80x960.npy", 3: "rand_DM_Input_80x960.npy", 6: "rand_DM_Input_80x960.npy"}
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", sorted(CASES))
+def test_sim_entry_end_to_end(case, capsys, tmp_path):
+    """`sim.main` as a user runs it (reference sim.py:197-213: load the frame, ONE forward, the bit-width banner) on the
+    reference's own 80x960 random inputs: the float result and the int8 `input.5` are the bytes the reference produced
+    (SHA-256 of its output / stored input.5 in *.full.npz).  sesr_x4_qat = BASELINE config 1's checkpoint (sr_qat_G.pth)."""
+    import hashlib
+    STORE.clear()
+    mflag = CASES[case]
+    z = np.load(os.path.join(GOLDEN, f"{case}.full.npz"), allow_pickle=False)
+    meta = json.loads(str(z["meta"]))
+    save = str(tmp_path / "out.npy")
+    y = sim.main(["--mflag", str(mflag), "--params", os.path.join(GOLDEN, f"{case}.params.npz"),
+                  "--input", os.path.join(GOLDEN, SIM_INPUT[mflag]), "--save", save])
+    out = capsys.readouterr().out
+    for line in (f"SIM_mflag: {mflag}", "QUAN_BIT: 8", "BIAS_BIT: 16", "PE_ACC_BIT: 18", "PE_ADD_BIT: 20", "REQUAN_BIT: 16", "REQUAN_N_MAX: 32"):
+        assert line in out, out
+    assert "mfma" in out            # the engines line: the HIP kernels ran, not a fallback
+    got = y.cpu().numpy()
+    assert list(got.shape) == meta["out_shape"]
+    assert hashlib.sha256(np.ascontiguousarray(got).tobytes()).hexdigest() == meta["sha"]["out"]
+    np.testing.assert_array_equal(np.load(save), got)
+    # input.5.pt: the int8 result before PixelShuffle
+    r = {5: 4, 3: 1, 6: 2}[mflag]
+    lowered = sim.splice(sim.float_model(mflag, params=os.path.join(GOLDEN, f"{case}.params.npz")))
+    lowered(torch.from_numpy(np.load(os.path.join(GOLDEN, SIM_INPUT[mflag]))).cuda())
+    q5 = torch.nn.functional.pixel_unshuffle(lowered.last_q.float(), r).to(torch.int8) if r > 1 else lowered.last_q
+    np.testing.assert_array_equal(q5.cpu().numpy(), z["input5"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ["sesr_x4", "sesr_x2_rand"])
+def test_dump_flags_write_an_output_pt_compatible_tree(case, tmp_path, monkeypatch):
+    """define.py's *_W_FLG switches (reference define.py:23-31): the forward leaves the reference's dump tensors in the store under
+    the reference's file names, `save_output_pt` writes the tree, `load_output_pt` reads it back -- and every tensor is the golden
+    one the reference wrote for this crop (input.K, pe_outputK_P, pe_add_outputK, conv.bias.quanK, requant constants)."""
+    STORE.clear()
+    for n in ("INPUT_W_FLG", "OUTPUT_PE_W_FLG", "OUTPUT_PE_ADD_W_FLG", "BIAS_QUAN_W_FLG", "REQUAN_FACTOR_W_FLG"):
+        monkeypatch.setattr(define, n, True)
+    model = sim.splice(sim.float_model(CASES[case], params=os.path.join(GOLDEN, f"{case}.params.npz")))
+    fx, meta = load_fixture(os.path.join(GOLDEN, f"{case}.crop.npz"))
+    model(torch.from_numpy(fx["x"]).cuda())
+    root = str(tmp_path / "output_pt")
+    STORE.save_output_pt(root)
+    assert os.path.isfile(os.path.join(root, "pe_out", "pe_output4_3.pt")) and os.path.isfile(os.path.join(root, "input", "input.5.pt"))
+    STORE.clear()
+    assert STORE.load_output_pt(root) > 40
+    for k in range(5):
+        np.testing.assert_array_equal(STORE[f"input/input.{k}"].numpy(), fx[f"input{k}"].astype(np.float32))
+        for p in range(4):
+            np.testing.assert_array_equal(STORE[f"pe_out/pe_output{k}_{p}"].numpy(), fx[f"pe_out{k}"][p].astype(np.float32))
+        np.testing.assert_array_equal(STORE[f"pe_add/pe_add_output{k}"].numpy(), fx[f"pe_add{k}"].astype(np.float32))
+        np.testing.assert_array_equal(STORE[f"bias/conv.bias.quan{k}"].numpy().reshape(-1), fx[f"add_const{k}"].astype(np.float32))
+        assert (STORE[f"requan_factor/requan_{k}_{k + 1}"], STORE[f"requan_factor/n_{k}_{k + 1}"]) == (meta["M"][k], meta["n"][k])
+        np.testing.assert_array_equal(STORE[f"weight/conv.weight.{k}"].numpy(), fx[f"Wq{k}"].astype(np.float32))
+    np.testing.assert_array_equal(STORE["input/input.5"].numpy(), fx["input5"].astype(np.float32))
+    assert (STORE["requan_factor/requan_res"], STORE["requan_factor/n_res"]) == (meta["M_res"], meta["n_res"])
+    STORE.clear()
+
+
 def test_calibration_graph_is_recognised_on_cpu():
     """mode-0 splice (reference test.py:79-106) is accepted and classified; running it needs the GPU."""
     import importlib

@@ -49,6 +49,9 @@ for li, k in enumerate(kernels):
         ent["valu_util"] = round(c.get("SQ_ACTIVE_INST_VALU", 0) * 4 / N_SIMD / cyc, 3)
         ent["mfma_util"] = round(c.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) / N_SIMD / cyc, 3)
         ent["lds_util"] = round(c.get("SQ_LDS_IDX_ACTIVE", 0) / 256 / cyc, 3)
+        if c.get("SQ_WAVE_CYCLES"):
+            ent["wait_inst_frac"] = round(c.get("SQ_WAIT_INST_ANY", 0) / c["SQ_WAVE_CYCLES"], 3)      # issue stalls / wave-cycles
+            ent["wait_any_frac"] = round(c.get("SQ_WAIT_ANY", 0) / c["SQ_WAVE_CYCLES"], 3)            # s_waitcnt + barriers
         if c.get("SQ_WAVES"):
             ent["wave_lifetime_cycles"] = round(c.get("SQ_WAVE_CYCLES", 0) * 4 / c["SQ_WAVES"])
     if "GRBM_GUI_ACTIVE" in c:
@@ -75,7 +78,7 @@ with open(os.path.join(root, "sq_counters.md"), "w") as f:
     f.write("|---|" + "---|" * len(rows) + "\n")
     for n in names:
         f.write(f"| {n} | " + " | ".join(f"{c.get(n, float('nan')):.4g}" for _, c in rows) + " |\n")
-    for key in ("kernel_cycles", "valu_util", "mfma_util", "lds_util", "wave_lifetime_cycles", "hbm_bytes_per_launch"):
+    for key in ("kernel_cycles", "valu_util", "mfma_util", "lds_util", "wait_inst_frac", "wait_any_frac", "wave_lifetime_cycles", "hbm_bytes_per_launch"):
         f.write(f"| **{key}** | " + " | ".join(str(summary[k].get(key, "")) for k, _ in rows) + " |\n")
 for k in kernels:
     e = summary[k]
