@@ -44,6 +44,12 @@ WORKLOADS = {
 }
 
 
+# Launch plan per workload: (streams, wg_budget), chosen by throughput in same-box A/Bs (tools/plan_ab.sh; profiles/README.md, round 3):
+# 1080p: 3 streams x 512 slots 14.5 k frames/s vs 2 streams x full chip 14.2 k; anything else: the round-2 plan.
+PLAN = {"sesr_x2_1080p": (3, 512)}
+PLAN_DEFAULT = (2, 0)
+
+
 def launch_bytes_per_px(bundle, first, count, in_f32):
     """Algorithmic HBM bytes per input pixel of ONE launch covering layers first..first+count-1:
     every NHWC16 int8 activation that crosses a launch boundary is written once and read once, the residual operand
@@ -79,14 +85,18 @@ def main():
     ap.add_argument("--batch", type=int, default=0, help="frames per step per GPU (0 = the workload's own)")
     ap.add_argument("--graph", action="store_true", help="replay each step as a captured HIP graph (Engine.capture): same kernels, one "
                                                          "host call per step instead of one per launch")
-    ap.add_argument("--streams", type=int, default=2,
+    ap.add_argument("--streams", type=int, default=0,
                     help="HIP streams the steps are enqueued on round-robin (frames are independent; each stream has "
-                         "its own workspace and output buffer) -- fills the launch/prologue/tail gaps between kernels")
+                         "its own workspace and output buffer) -- fills the launch/prologue/tail gaps between kernels.  0 = the "
+                         "workload's tuned plan (PLAN): 3 for the 1080p headline, 2 otherwise")
     ap.add_argument("--workload", default="sesr_x2_1080p", choices=sorted(WORKLOADS))
     ap.add_argument("--engine", default="auto", choices=["auto", "dot4", "mfma"])
     ap.add_argument("--no-fuse", action="store_true", help="one launch per layer (no fused hidden trio)")
     ap.add_argument("--fuse", type=int, default=1, choices=[0, 1, 2], help="0 per layer, 1 (default) hidden trios, 2 + fused front")
-    ap.add_argument("--wg-budget", type=int, default=0)
+    ap.add_argument("--wg-budget", type=int, default=-1,
+                    help="workgroup slots a launch may fill (sesrq_options.wg_budget; 0 = one full round of the chip).  -1 = the workload's "
+                         "tuned plan (PLAN): 512 of the 1024 slots for the 1080p headline, so that kernels of three frames stay co-resident "
+                         "on every CU instead of meeting only at their tails")
     ap.add_argument("--timing-iters", type=int, default=200, help="forwards of the per-launch HIP-event timing (roofline)")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend of the timing fence (nccl = RCCL; gloo + --share-gpu rehearses N > 1 on a 1-GPU box)")
@@ -98,6 +108,11 @@ def main():
 
     if args.repeats <= 0:
         args.repeats = max(5, -(-1500 // max(1, args.steps)))
+    plan_streams, plan_budget = PLAN.get(args.workload, PLAN_DEFAULT)
+    if args.streams <= 0:
+        args.streams = plan_streams
+    if args.wg_budget < 0:
+        args.wg_budget = plan_budget
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus > 1 and world == 1:
         # not launched by torchrun: start the ranks as children (before anything touches the GPU)
@@ -296,7 +311,7 @@ def main():
                   "vs_baseline": None, "dtype": "i8", "data": "synthetic",
                   "host_enqueue_us_per_step": None if res["host_enqueue_s_per_step"] is None else round(res["host_enqueue_s_per_step"] * 1e6, 1), "repeats": args.repeats, "blocks_fps": [round(args.steps * total_frames_per_step / e, 1) for e in res["elapsed"]], "spread": {"min": round(fps_all[0], 2), "median": round(fps, 2), "max": round(fps_all[-1], 2)},
                   "config": {"workload": desc, "name": args.workload, "frames_per_step_per_gpu": B, "frames_per_step": total_frames_per_step,
-                             "streams": NS, "hip_graph": bool(graphs), "input_pool": f"{POOL} distinct resident frames, rotated per step",
+                             "streams": NS, "wg_budget": args.wg_budget, "hip_graph": bool(graphs), "input_pool": f"{POOL} distinct resident frames, rotated per step",
                              "in": [B, cin, H, W], "out": list(shapes[-1]), "input_dtype": "f32", "output_dtype": "i8",
                              "weights": [("reference random-init net, calibrated by the reference" if "rand" in f else
                                           "reference checkpoint, calibrated by this package (parity unpinned)" if "bundle" in f else
@@ -352,15 +367,19 @@ def e2e_leg(torch, engines, pool, outs, B, frames=96, depth=3, int8_in=False):
                 ev_out[b].record(s_out)
         torch.cuda.synchronize()
     run(2 * depth)
-    t0 = time.perf_counter()
-    run(frames)
-    dt = time.perf_counter() - t0
+    dts = []
+    for _ in range(3):          # the copies share the DMA / blit path with whatever else the box does: median of three passes
+        t0 = time.perf_counter()
+        run(frames)
+        dts.append(time.perf_counter() - t0)
+    dt = sorted(dts)[1]
     mb_in = hin[0].numel() * hin[0].element_size() / 1e6
     mb_out = hout[0].numel() / 1e6
     return {"value": round(frames * B / dt, 2), "unit": "frames/s", "bound": "pcie", "input_dtype": "i8" if int8_in else "f32",
             "h2d_MB_per_step": round(mb_in, 2), "d2h_MB_per_step": round(mb_out, 2),
             "pcie_GBps": round((mb_in + mb_out) * frames / dt / 1e3, 2),
-            "note": f"pinned host buffers, H2D / kernels / D2H on three streams, {depth} frames in flight, {frames} steps; never `value`"}
+            "passes_fps": [round(frames * B / t, 1) for t in dts],
+            "note": f"pinned host buffers, H2D / kernels / D2H on three streams, {depth} frames in flight, median of 3 passes of {frames} steps; never `value`"}
 
 
 if __name__ == "__main__":
