@@ -9,6 +9,13 @@ typedef unsigned v4u __attribute__((ext_vector_type(4)));
 typedef unsigned v2u __attribute__((ext_vector_type(2)));
 typedef float v2f __attribute__((ext_vector_type(2)));
 
+#ifndef SESRQ_DIRECT_ROWS
+#define SESRQ_DIRECT_ROWS 0    /* A/B knob: 1 = hidden-layer rows leave (and the residual operand arrives) as one dword per lane and row
+                                  (lane (n, g) owns word g of pixel n: 256 contiguous bytes per wave) instead of 4x4 lane-group transposes
+                                  around one 16-byte access per lane.  Measured round 3 (same box, 3 rounds): 8 v_permlane*_swap fewer per
+                                  four rows, but four times the store / load instructions: first layer 18.9 -> 20.0 us, trio 37.3 -> 39.7 us,
+                                  14.45 k -> 14.1 k frames/s.  Not used. */
+#endif
 #ifndef SESRQ_U8
 #define SESRQ_U8 1      /* A/B knob: 0 = med3 + magic add + perm epilogue everywhere (round_pack), 1 = round_pack_u8 where every zero point is -128 */
 #endif
@@ -232,6 +239,7 @@ __device__ __forceinline__ void transpose4(unsigned w[4]) {
 struct RowIO {
     __amdgpu_buffer_rsrc_t out, rc_in, rc_out;
     int voff;        // lane (n, r' = g): byte offset of pixel (y0 + g, gx) or out-of-range
+    int voffw;       // lane (n, g): byte offset of word g of pixel (y0, gx) or out-of-range
     int row_bytes;   // W * 16
 };
 __device__ __forceinline__ RowIO make_rowio(const ConvArgs &a, int n_img, int y0, int gx, int g) {
@@ -243,13 +251,20 @@ __device__ __forceinline__ RowIO make_rowio(const ConvArgs &a, int n_img, int y0
     io.rc_out = __builtin_amdgcn_make_buffer_rsrc((char *)a.rc_out + (size_t)n_img * img, 0, bytes, 0x00020000);
     io.row_bytes = a.W * 16;
     io.voff = (gx < a.W) ? ((y0 + g) * a.W + gx) * 16 : (int)0x80000000;
+    io.voffw = (gx < a.W) ? (y0 * a.W + gx) * 16 + 4 * g : (int)0x80000000;
     return io;
 }
 __device__ __forceinline__ void store_rows4(__amdgpu_buffer_rsrc_t rs, const RowIO &io, int y4, unsigned w[4]) {
-    transpose4(w);
-    const v4u v = {w[0], w[1], w[2], w[3]};
     // aux 16 = sc1: the activation tensor is only read again by the NEXT kernel; measured against the default policy,
     // sc0|sc1 and nt on 1080p: sc1 -6 % on the first layer, -3..5 % on the hidden layers when frames overlap; nt +12 %
+    if constexpr (SESRQ_DIRECT_ROWS) {
+        // compute layout straight to memory: one dword per lane and row (64 lanes = 16 pixels x 4 words = two full 128-byte lines)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) __builtin_amdgcn_raw_buffer_store_b32(w[r], rs, io.voffw + (y4 + r) * io.row_bytes, 0, 16);
+        return;
+    }
+    transpose4(w);
+    const v4u v = {w[0], w[1], w[2], w[3]};
     // The row offset rides in the VECTOR offset, soffset = 0, on purpose: gfx950 needs one wait state between a dwordx4 store with
     // an SGPR soffset and a VALU write of its data registers (tools/store_hazard_probe.hip: 2000 of 8.4 M stores carried the
     // overwritten register at 0 wait states), LLVM's hazard recognizer assumes such a store needs none, and hipcc 7.2 did place a
@@ -263,9 +278,15 @@ template <int EPI, bool RC, bool BIASED, bool U8 = false, class AT>
 __device__ __forceinline__ void emit_rows4(const int s4[4][4], const AT &a, const RowIO &io, int y4, float zlo) {
     unsigned w[4];
     if constexpr (EPI == EPI_PRERES) {
-        const v4u rv = __builtin_amdgcn_raw_buffer_load_b128(io.rc_in, io.voff, y4 * io.row_bytes, 0);
-        unsigned rcw[4] = {rv[0], rv[1], rv[2], rv[3]};
-        transpose4(rcw);
+        unsigned rcw[4];
+        if constexpr (SESRQ_DIRECT_ROWS) {       // the residual operand in compute layout: word g of pixel n, one dword per row
+#pragma unroll
+            for (int r = 0; r < 4; ++r) rcw[r] = __builtin_amdgcn_raw_buffer_load_b32(io.rc_in, io.voffw + (y4 + r) * io.row_bytes, 0, 0);
+        } else {
+            const v4u rv = __builtin_amdgcn_raw_buffer_load_b128(io.rc_in, io.voff, y4 * io.row_bytes, 0);
+            rcw[0] = rv[0]; rcw[1] = rv[1]; rcw[2] = rv[2]; rcw[3] = rv[3];
+            transpose4(rcw);
+        }
 #pragma unroll
         for (int r = 0; r < 4; ++r) w[r] = epi_preres<BIASED, U8>(s4[r], rcw[r], a);
     } else {

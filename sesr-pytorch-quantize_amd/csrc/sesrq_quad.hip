@@ -261,6 +261,7 @@ __global__ __launch_bounds__(256) void mfma_quad_kernel(const QuadArgs a) {
     auto outer = [&](int Y, const unsigned rc012[3], const v4i (&Wk)[3]) __attribute__((always_inline)) {
         const int4 *p = bufB + rdcol;
         io.voff = col_out ? voff_c + Y * io.row_bytes : OOB;
+        io.voffw = col_out ? gx * 16 + 4 * g + Y * io.row_bytes : OOB;
         const v4i acck = ld_frag(accL + 8 + g);
         // rows Y+3 .. Y+7 of the layer-0 output are still at IN positions 3 .. 7 (the shift only rewrote positions 0 .. 2)
         unsigned rc[TH];

@@ -162,6 +162,7 @@ __global__ __launch_bounds__(256) void mfma_trio_kernel(const TrioArgs a) {
         constexpr int NR = decltype(NRC)::value;
         const int4 *p = bufB + rdcol;
         io.voff = col_out ? voff_c + Y * io.row_bytes : OOB;
+        io.voffw = col_out ? gx * 16 + 4 * g + Y * io.row_bytes : OOB;
         v4i B0 = ld_frag(p), B1 = ld_frag(p + TP);
 #pragma unroll
         for (int y4 = 0; y4 < NR; y4 += 4) {
