@@ -156,6 +156,41 @@ static void pack_mfma_frags(const sesrq_layer_desc &d, int kind, bool general, i
             }
 }
 
+// Sparse hybrid images of a 3-channel first layer (HYBS, sesrq_mfma_common.h): header = add constants in row order, then the
+// "other two channels" image and the risky channel's image, 64 lanes x 16 stored bytes each.  Stored byte 2j + e of lane (m, ga)
+// = weight of channel ch_e at the tap that B lane group gb = 2 (ga & 1) + (j >> 2) holds in register r = 4 (ga >> 1) + (j & 3):
+// r < 4: tap (ky = gb, kx = r); r >= 4: f5_tr(gb) + f5_pt(r - 4)  (the dense MFMA_F5 scheme, K-chunks 0 and 1 side by side).
+static void pack_f5_sparse(const sesrq_layer_desc &d, int risky_pe, std::vector<int> &out) {
+    const int taps = d.k * d.k;
+    out.assign((size_t)16 + 2 * 64 * 4, 0);
+    for (int m = 0; m < 16; ++m) { const int oc = (m >> 2) + 4 * (m & 3); out[m] = oc < d.oc ? d.add_const[oc] : 0; }
+    int others[2], no = 0;
+    for (int c = 0; c < 3; ++c) if (c != risky_pe) others[no++] = c;
+    signed char *bytes = reinterpret_cast<signed char *>(out.data() + 16);
+    for (int img = 0; img < 2; ++img)
+        for (int lane = 0; lane < 64; ++lane)
+            for (int s = 0; s < 16; ++s) {
+                const int m = lane & 15, ga = lane >> 4, j = s >> 1, e = s & 1;
+                const int gb = 2 * (ga & 1) + (j >> 2), r = 4 * (ga >> 1) + (j & 3);
+                int ky, kx;
+                if (r < 4) { ky = gb; kx = r; }
+                else {
+                    int tr_r, tr_c, pt_r, pt_c;
+                    f5_tr(gb, tr_r, tr_c);
+                    f5_pt(r - 4, pt_r, pt_c);
+                    ky = tr_r + pt_r; kx = tr_c + pt_c;
+                    const bool in_l = (ky == 4 && kx <= 4) || (kx == 4 && ky <= 4);
+                    if (!in_l || (gb == 2 && r - 4 == 1)) ky = -1;          // (4,2) belongs to lane group 0
+                }
+                const int ch = img == 0 ? others[e] : (e == 0 ? risky_pe : -1);
+                const int oc = (m >> 2) + 4 * (m & 3);
+                int w = 0;
+                if (ky >= 0 && ky < d.k && kx >= 0 && kx < d.k && ch >= 0 && ch < d.ic && oc < d.oc)
+                    w = d.w[((size_t)oc * d.ic + ch) * taps + ky * d.k + kx];
+                bytes[((size_t)img * 64 + lane) * 16 + s] = (signed char)w;
+            }
+}
+
 static int replicate_byte(int v) {
     const int b = v & 0xff;
     return b | (b << 8) | (b << 16) | (b << 24);
@@ -306,6 +341,16 @@ int sesrq_create(const sesrq_net_desc *d, const sesrq_options *opts, sesrq_net *
                     return 1;
                 }
             }
+            if (lp.mfma_kind == MFMA_F5 && lp.d_afrag_others && l.ic == 3 && __builtin_ctz(lp.risky_mask) < 3) {
+                std::vector<int> fr;
+                pack_f5_sparse(l, __builtin_ctz(lp.risky_mask), fr);
+                if (hipMalloc((void **)&lp.d_afrag_sparse, fr.size() * sizeof(int)) != hipSuccess ||
+                    hipMemcpy(lp.d_afrag_sparse, fr.data(), fr.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess) {
+                    set_error("sesrq_create: device upload failed");
+                    sesrq_destroy(net);
+                    return 1;
+                }
+            }
             if (k == L - 1 && lp.mfma_kind == MFMA_H5 && l.oc <= 4) {
                 std::vector<int> fr;
                 pack_mfma_frags(l, MFMA_H5P, true, 4, d->pixel_shuffle, fr);
@@ -381,6 +426,7 @@ void sesrq_destroy(sesrq_net *net) {
         if (lp.d_afrag_merged) (void)hipFree(lp.d_afrag_merged);
         if (lp.d_afrag_pesplit) (void)hipFree(lp.d_afrag_pesplit);
         if (lp.d_afrag_others) (void)hipFree(lp.d_afrag_others);
+        if (lp.d_afrag_sparse) (void)hipFree(lp.d_afrag_sparse);
     }
     delete net;
 }
@@ -559,7 +605,7 @@ static int forward_impl(const sesrq_net *net, const void *in, int in_dtype, void
             a.afrag = eff.general ? lp.d_afrag_general : lp.d_afrag_merged;
             // exactly one PE can saturate (and nothing forces the full per-PE path): merged chain + that PE's chain
             const bool one_pe = lp.general && !net->force_general && !dbg && lp.d_afrag_others && net->acc_bits == 18 && net->add_bits == 20;
-            if (one_pe) { a.afrag = lp.d_afrag_others; a.afrag2 = lp.d_afrag_general; a.risky_pe = __builtin_ctz(lp.risky_mask); }
+            if (one_pe) { a.afrag = lp.d_afrag_others; a.afrag2 = lp.d_afrag_general; a.risky_pe = __builtin_ctz(lp.risky_mask); a.afrag_sp = lp.d_afrag_sparse; }
             if (lp.d_afrag_pesplit) a.afrag = lp.d_afrag_pesplit;
             if (launch_mfma(lp, a, src, epi, eff.general, st, one_pe, tap_mfma)) return 1;
         } else if (launch_dot4(eff, a, src, epi, st)) return 1;

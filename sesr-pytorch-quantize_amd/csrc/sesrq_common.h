@@ -127,6 +127,7 @@ struct ConvArgs {
     const float *anchor;     // EPI_LAST: fp32 input frame (N,C,H,W) added, nearest-upsampled, to out_f; or NULL
     const int *wpk;          // dot4: packed weights [tap][OCP][4] dwords (see pack_weights)
     const int4 *afrag;       // mfma: [4] add-constant words (row order) + A fragments [F][64] (pack_mfma_frags)
+    const int4 *afrag_sp;    // first layer, hybrid, 3 channels: 2:4-sparse images [4 header][others: 64 lanes][risky PE: 64 lanes] (pack_f5_sparse) or NULL
     const int4 *afrag2;      // mfma hybrid mode: afrag = merged image WITHOUT the risky PE, afrag2 = per-PE (general) image; risky_pe selects its chain
     int risky_pe;
     int *dbg_pe;             // (N,4,OC,H,W) int32 or NULL
@@ -195,6 +196,7 @@ struct LayerPlan {
     int4 *d_afrag_general = nullptr; // device
     int4 *d_afrag_merged = nullptr;  // device
     int4 *d_afrag_pesplit = nullptr; // device: last layer with OC <= 4 (MFMA_H5P image), else NULL
+    int4 *d_afrag_sparse = nullptr;  // device: first layer, exactly one risky PE, 3 input channels: sparse hybrid images, else NULL
     int4 *d_afrag_others = nullptr;  // device: exactly one risky PE: merged image with that PE's channels zeroed, else NULL
     std::string engine_dot4, engine_mfma;
     ConvArgs base;           // constant fields prefilled

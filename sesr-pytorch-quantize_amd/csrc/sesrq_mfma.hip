@@ -668,6 +668,12 @@ struct StageFrame {
     }
 };
 
+#ifndef SESRQ_F5_SPARSE
+#define SESRQ_F5_SPARSE 1     /* A/B knob: 0 = the hybrid first layer on dense MFMAs (two per chain) */
+#endif
+#ifndef SESRQ_F5_UNROLL
+#define SESRQ_F5_UNROLL 0     /* A/B knob: 1 = the three 4-row groups of a first-layer tile as one basic block */
+#endif
 #ifndef SESRQ_F5_TH
 #define SESRQ_F5_TH 12     /* 12 rows: 8 is 1.3 us faster alone (shorter prologue), 12 and 16 re-quantise fewer halo pixels; with two frames in flight 12 gave +1 % (same-box A/B, round 2) */
 #endif
@@ -688,11 +694,21 @@ __device__ __forceinline__ void mfma_f5_body(const ConvArgs &a, int4 *buf0, int4
     if constexpr (BIASED) { ac.x += MAGIC_I; ac.y += MAGIC_I; ac.z += MAGIC_I; ac.w += MAGIC_I; }
     constexpr int NPE = GENERAL ? 4 : 1;
     v4i A[2][NPE];
-#pragma unroll
-    for (int f = 0; f < 2; ++f)
-#pragma unroll
-        for (int p = 0; p < NPE; ++p) A[f][p] = ld_frag(fr + 4 + (f * NPE + p) * 64 + l);
     v4i AR[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
+    int idx_o = 0, idx_r = 0;           // HYBS: positions of the kept elements inside a pixel's four K slots, the same for every group
+    if constexpr (MODE == HYBS) {       // A[0][0] = the other two channels' sparse image, AR[0] = the risky channel's
+        A[0][0] = ld_frag(a.afrag_sp + 4 + l);
+        A[1][0] = A[0][0];
+        AR[0] = ld_frag(a.afrag_sp + 4 + 64 + l);
+        const int pr = a.risky_pe, ca = pr == 0 ? 1 : 0, cb = pr == 2 ? 1 : 2;
+        idx_o = (ca | (cb << 2)) * 0x11111111;
+        idx_r = (pr | (((pr + 1) & 3) << 2)) * 0x11111111;
+    } else {
+#pragma unroll
+        for (int f = 0; f < 2; ++f)
+#pragma unroll
+            for (int p = 0; p < NPE; ++p) A[f][p] = ld_frag(fr + 4 + (f * NPE + p) * 64 + l);
+    }
     if constexpr (MODE == HYB) {
 #pragma unroll
         for (int f = 0; f < 2; ++f) AR[f] = ld_frag(a.afrag2 + 4 + (f * 4 + a.risky_pe) * 64 + l);
@@ -719,7 +735,11 @@ __device__ __forceinline__ void mfma_f5_body(const ConvArgs &a, int4 *buf0, int4
         typedef const int __attribute__((address_space(3))) *lds_int_t;
         const unsigned tb = (unsigned)(size_t)(const __attribute__((address_space(3))) void *)cp;     // LDS byte address of the tile
         unsigned b0 = tb + addr0, b1 = tb + addr1;
+#if SESRQ_F5_UNROLL
+#pragma unroll
+#else
 #pragma unroll 1
+#endif
         for (int y4 = 0; y4 < F5_TH; y4 += 4) {
             int s4[4][4];
 #pragma unroll
@@ -729,7 +749,7 @@ __device__ __forceinline__ void mfma_f5_body(const ConvArgs &a, int4 *buf0, int4
                 asm("" : "+v"(b0), "+v"(b1));
                 const lds_int_t p0 = (lds_int_t)(size_t)(b0 + 4 * r), p1 = (lds_int_t)(size_t)(b1 + 4 * r);
                 const v4i B0 = {p0[0], p0[PITCH], p0[2 * PITCH], p0[3 * PITCH]}, B1 = {p1[0], p1[1], p1[1 + PITCH], p1[1 + 2 * PITCH]};
-                v4i acc[GENERAL ? 4 : (MODE == HYB ? 2 : 1)];
+                v4i acc[GENERAL ? 4 : 1];
                 const v4i zero = {0, 0, 0, 0};
                 if constexpr (GENERAL) {
 #pragma unroll
@@ -741,7 +761,13 @@ __device__ __forceinline__ void mfma_f5_body(const ConvArgs &a, int4 *buf0, int4
                     finish_sums<MODE>(s4[r], acc, ac, a);
                 } else {
                     const v4i acc0 = {ac.x, ac.y, ac.z, ac.w};
-                    if constexpr (MODE == HYB) {       // same B operands, A masked to the risky PE's channel
+                    if constexpr (MODE == HYBS) {      // one sparse MFMA per chain over all 32 pixel taps (B0 and B1 side by side)
+                        const v8i B8 = {B0[0], B0[1], B0[2], B0[3], B1[0], B1[1], B1[2], B1[3]};
+                        v4i rk = smfmac(AR[0], B8, acc0, idx_r);
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) rk[i] = med3_biased(rk[i], rlo[i], rhi[i]);
+                        acc[0] = smfmac(A[0][0], B8, rk, idx_o);
+                    } else if constexpr (MODE == HYB) {       // same B operands, A masked to the risky PE's channel
                         v4i rk = mfma(AR[0], B0, acc0);
                         rk = mfma(AR[1], B1, rk);
 #pragma unroll
@@ -888,6 +914,7 @@ int launch_mfma(const LayerPlan &lp, const ConvArgs &a_in, int src, int epi, boo
 #define SESRQ_F5(...)                                                                    \
     do {                                                                                 \
         if (mode == MERGED) launch(mfma_f5_kernel_w4<MERGED, __VA_ARGS__>, a, st, F5_TH);       \
+        else if (mode == HYB && a.afrag_sp && SESRQ_F5_SPARSE) launch(mfma_f5_kernel_w4<HYBS, __VA_ARGS__>, a, st, F5_TH);        \
         else if (mode == HYB) launch(mfma_f5_kernel_w4<HYB, __VA_ARGS__>, a, st, F5_TH);        \
         else if (mode == GEN_STD) launch(mfma_f5_kernel<GEN_STD, __VA_ARGS__>, a, st, F5_TH);   \
         else launch(mfma_f5_kernel<GEN_ANY, __VA_ARGS__>, a, st, F5_TH);                        \

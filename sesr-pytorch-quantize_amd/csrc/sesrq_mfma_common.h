@@ -23,13 +23,23 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 constexpr float MAGIC = 12582912.f;   // 1.5 * 2^23
 
 // accumulate modes
-enum { MERGED = 0, GEN_STD = 1, GEN_ANY = 2, HYB = 3, GEN_TAP = 4 };   // GEN_STD: 18/20-bit clamps as literals; HYB: one risky PE
+enum { MERGED = 0, GEN_STD = 1, GEN_ANY = 2, HYB = 3, GEN_TAP = 4, HYBS = 5 };   // GEN_STD: 18/20-bit clamps as literals; HYB: one risky PE
 // GEN_TAP = GEN_ANY + the reference's PE dump taps (pe_outputK_P / pe_add_outputK, myQL/quan_func.py:372-378, 439-443) written by
 // the MFMA per-PE kernels themselves (sesrq_forward_debug): the debug forward, never the production one
+// HYBS = HYB of a 3-channel first layer on the 2:4 structured-sparse MFMA (v_smfmac_i32_16x16x128_i8: twice the K of the dense
+// instruction in the same 16 cycles, measured): a pixel is one dword = one group of four K slots (3 channel bytes + a zero byte), the
+// "other PEs" chain has two non-zero weights per group and the risky PE's chain one -- both are 2:4 images by construction, so each
+// chain is ONE instruction over all 32 pixel taps instead of two dense ones.
 __host__ __device__ constexpr bool mode_general(int m) { return m == GEN_STD || m == GEN_ANY || m == GEN_TAP; }
 __host__ __device__ constexpr bool mode_biased(int m) { return m != GEN_ANY && m != GEN_TAP; }
 
 __device__ __forceinline__ v4i mfma(v4i a, v4i b, v4i c) { return __builtin_amdgcn_mfma_i32_16x16x64_i8(a, b, c, 0, 0, 0); }
+typedef int v8i __attribute__((ext_vector_type(8)));
+// D += A_sparse(16 x 128, stored 16 x 64) x B(128 x 16).  Operand layout (measured, tools/smfmac_probe.hip): B lane (n, gb) register r
+// = one group of four K slots; A lane (m, ga) stored bytes 2j, 2j+1 (j = 0..7) = the two kept elements of the group that B holds in
+// lane group gb = 2 (ga & 1) + (j >> 2), register r = 4 (ga >> 1) + (j & 3); idx nibble j = position of element 0 | position of
+// element 1 << 2 inside the group.
+__device__ __forceinline__ v4i smfmac(v4i a, v8i b, v4i c, int idx) { return __builtin_amdgcn_smfmac_i32_16x16x128_i8(a, b, c, idx, 0, 0); }
 __device__ __forceinline__ float med3(float v, float lo, float hi) { return __builtin_amdgcn_fmed3f(v, lo, hi); }
 __device__ __forceinline__ int clampi3(int v, int lo, int hi) { return min(max(v, lo), hi); }
 // the same for BIASED sums (bits = MAGIC_I + s = the float 1.5 * 2^23 + s, |s| < 2^22: one binade, so float order == integer order)

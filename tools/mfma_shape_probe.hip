@@ -94,6 +94,18 @@ __global__ __launch_bounds__(256) void k(unsigned *out, int iters, float mf, flo
             EPI13(p, q, w)
             keep ^= w;
         }
+    } else if constexpr (KIND == 8) {                  // three dependent sparse MFMAs 16x16x128 (2:4 structured A): cycles per instruction?
+        v4i acc = {0, 0, 0, 0};
+        const v4i As = {1, 2, 3, 4};
+        typedef int v8i __attribute__((ext_vector_type(8)));
+        const v8i Bd = {5, (int)threadIdx.x, 7, 8, 9, 10, 11, 12};
+        const int idx = 0x44444444;
+        for (int i = 0; i < iters; ++i) {
+            asm volatile("v_smfmac_i32_16x16x128_i8 %0, %1, %2, %3" : "+v"(acc) : "v"(As), "v"(Bd), "v"(idx));
+            asm volatile("v_smfmac_i32_16x16x128_i8 %0, %1, %2, %3" : "+v"(acc) : "v"(As), "v"(Bd), "v"(idx));
+            asm volatile("v_smfmac_i32_16x16x128_i8 %0, %1, %2, %3" : "+v"(acc) : "v"(As), "v"(Bd), "v"(idx));
+        }
+        keep ^= (unsigned)acc[0];
     } else {                                            // b32 / b32cvt: 2 rows x 32 pixels = 4 a16 rows per iteration
         v16i zero;
         for (int j = 0; j < 16; ++j) zero[j] = 0;
@@ -139,7 +151,7 @@ int main() {
     unsigned *d; (void)hipMalloc(&d, 256 * 4 * 256 * 4);
     for (int rep = 0; rep < 2; ++rep) {
         run<0>("a16", d); run<1>("a16cvt", d); run<2>("a16pipe", d); run<3>("b32", d); run<4>("b32cvt", d);
-        run<5>("chain", d); run<6>("epi13", d); run<7>("a16indep", d);
+        run<5>("chain", d); run<6>("epi13", d); run<7>("a16indep", d); run<8>("smfmac128", d);
     }
     return 0;
 }
