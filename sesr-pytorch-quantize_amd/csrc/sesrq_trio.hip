@@ -21,6 +21,11 @@
 
 #include <algorithm>
 #include <mutex>
+#include <type_traits>
+
+#ifndef SESRQ_TRIO_NOPAD
+#define SESRQ_TRIO_NOPAD 1      /* A/B knob: 0 = the inner phases always run their per-row pad select */
+#endif
 
 #include "sesrq_mfma_common.h"
 
@@ -110,6 +115,7 @@ __global__ __launch_bounds__(256) void mfma_trio_kernel(const TrioArgs a) {
     const int c = 16 * w + n, gx = x0 + c;
     const bool col_in = (gx >= 0) & (gx < a.W);                   // inner layers: inside the frame, else pad
     const bool col_out = (c >= 2) & (c < 2 + TV) & (gx < a.W);    // valid output columns of the strip
+    const bool strip_in = (x0 >= 0) & (x0 + 63 < a.W);            // wave-uniform: every computed column of the strip is inside the frame
     const int rdcol = c + g;                                       // window pixel of tap kx = g (window column = computed column + 1)
     const int wrcol = (c + 1) * 4 + g;                             // window dword of this lane's output word
 
@@ -136,8 +142,12 @@ __global__ __launch_bounds__(256) void mfma_trio_kernel(const TrioArgs a) {
     // weights in LDS to stay at 4 waves per SIMD) ran 11 % SLOWER alone (42 vs 38 us at 1080p) and the same with two frames in
     // flight (same-box A/B, round 2): the instruction count is what bounds this kernel, not the order inside one wave.
     // rows i0 .. i1-1 of the step: (0, 8) a full step, (4, 8) / (6, 8) the cold start, (0, 4) the half step that closes a run
-    auto inner = [&](auto KC, auto I0, auto I1, const int4 *src, int4 *dst, int row0) __attribute__((always_inline)) {
+    // PADC: std::true_type = the pad word is selected in for pixels outside the frame; std::false_type = the caller knows that every row
+    // and column this call produces lies inside the frame (interior strips, steps away from the bottom edge: ~85 % of a 1080p frame):
+    // no per-row compare / select (1 VALU + 4 SALU of the ~13 + 8 per row)
+    auto inner = [&](auto KC, auto I0, auto I1, const int4 *src, int4 *dst, int row0, auto PADC) __attribute__((always_inline)) {
         constexpr int K = decltype(KC)::value, i0 = decltype(I0)::value, i1 = decltype(I1)::value;
+        constexpr bool PAD = decltype(PADC)::value;
         const TrioLayer &L = a.l[K];
         const int4 *p = src + rdcol;
         unsigned *d = reinterpret_cast<unsigned *>(dst) + wrcol;
@@ -151,9 +161,11 @@ __global__ __launch_bounds__(256) void mfma_trio_kernel(const TrioArgs a) {
             B0 = B1; B1 = B2;
             const int s[4] = {acc[0], acc[1], acc[2], acc[3]};
             unsigned q = epi_mid<true, U8>(s, L, L.zlo);
-            const int row = row0 + i;
-            const bool rok = (row >= 0) & (row < a.H);
-            q = (rok & col_in) ? q : (unsigned)L.pad_next;
+            if constexpr (PAD) {
+                const int row = row0 + i;
+                const bool rok = (row >= 0) & (row < a.H);
+                q = (rok & col_in) ? q : (unsigned)L.pad_next;
+            }
             d[(2 + i) * TP * 4] = q;
         }
     };
@@ -199,13 +211,13 @@ __global__ __launch_bounds__(256) void mfma_trio_kernel(const TrioArgs a) {
         st.store<true>(bufI, a.pad_in, tid);
         __syncthreads();
         st.load<false>(a, Y + TH + 3);
-        inner(IC0(), IC4(), IC8(), bufI, bufA, Y + 2);
+        inner(IC0(), IC4(), IC8(), bufI, bufA, Y + 2, std::true_type());
         int4 shI = make_int4(0, 0, 0, 0);
         if (tid < 2 * TP) shI = bufI[TH * TP + tid];
         __syncthreads();
         if (tid < 2 * TP) bufI[tid] = shI;
         st.store<false>(bufI, a.pad_in, tid);
-        inner(IC1(), IC6(), IC8(), bufA, bufB, Y + 1);
+        inner(IC1(), IC6(), IC8(), bufA, bufB, Y + 1, std::true_type());
         __syncthreads();
         shift(bufA);
         __syncthreads();
@@ -215,7 +227,9 @@ __global__ __launch_bounds__(256) void mfma_trio_kernel(const TrioArgs a) {
         const bool more = Y + TH < y_end;                        // another step (full or half) follows
         if (more) st.load<false>(a, Y + TH + 3);                 // its new input rows, consumed after the first barrier
         shift(bufB);                                             // layer-b rows Y-1, Y (phase c of the previous step is done)
-        inner(IC0(), IC0(), IC8(), bufI, bufA, Y + 2);
+        const bool nopad = SESRQ_TRIO_NOPAD && strip_in && (Y + TH + 2 <= a.H);      // wave-uniform: rows Y+1 .. Y+9, all 64 columns inside
+        if (nopad) inner(IC0(), IC0(), IC8(), bufI, bufA, Y + 2, std::false_type());
+        else inner(IC0(), IC0(), IC8(), bufI, bufA, Y + 2, std::true_type());
         int4 shI = make_int4(0, 0, 0, 0);
         if (tid < 2 * TP) shI = bufI[TH * TP + tid];
         __syncthreads();
@@ -223,7 +237,8 @@ __global__ __launch_bounds__(256) void mfma_trio_kernel(const TrioArgs a) {
             if (tid < 2 * TP) bufI[tid] = shI;
             st.store<false>(bufI, a.pad_in, tid);
         }
-        inner(IC1(), IC0(), IC8(), bufA, bufB, Y + 1);
+        if (nopad) inner(IC1(), IC0(), IC8(), bufA, bufB, Y + 1, std::false_type());
+        else inner(IC1(), IC0(), IC8(), bufA, bufB, Y + 1, std::true_type());
         __syncthreads();
         shift(bufA);
         outer(IC8(), Y);
@@ -231,9 +246,9 @@ __global__ __launch_bounds__(256) void mfma_trio_kernel(const TrioArgs a) {
     }
     if (Y < y_end) {                                             // the closing half step: output rows Y .. Y+3
         shift(bufB);
-        inner(IC0(), IC0(), IC4(), bufI, bufA, Y + 2);
+        inner(IC0(), IC0(), IC4(), bufI, bufA, Y + 2, std::true_type());
         __syncthreads();
-        inner(IC1(), IC0(), IC4(), bufA, bufB, Y + 1);
+        inner(IC1(), IC0(), IC4(), bufA, bufB, Y + 1, std::true_type());
         __syncthreads();
         outer(IC4(), Y);
     }
