@@ -38,6 +38,9 @@
 
 namespace sesrq {
 
+#ifndef SESRQ_STAGE_INTERIOR
+#define SESRQ_STAGE_INTERIOR 1     /* A/B knob: 0 = every staged pixel goes through the pad select */
+#endif
 constexpr int MTW = 64;   // tile width : 4 waves x 16 pixels
 #ifndef SESRQ_MTH
 #define SESRQ_MTH 8
@@ -173,9 +176,13 @@ struct StageNHWC16 {
     static constexpr int NIT = (SH * SW + 255) / 256;
     v4u v[NIT];
     bool ok[NIT];
+    bool interior;               // wave-uniform: every staged pixel of the tile lies inside the frame -> no pad selects in store()
     int voff[NIT], ty[NIT];      // per-lane byte offset of the pixel in tile row space; tile row of the pixel
     __amdgpu_buffer_rsrc_t rs;
     int row_bytes;
+    __device__ __forceinline__ void set_interior(const ConvArgs &a, int x0, int y0) {
+        interior = SESRQ_STAGE_INTERIOR && (x0 - R >= 0) && (x0 - R + SW <= a.W) && (y0 - R >= 0) && (y0 - R + SH <= a.H);
+    }
     // Addresses are lane constants + ONE scalar per tile (soffset = y0 * W * 16): the loop issues its
     // loads without touching a VGPR, so nothing forces a wait on the previous tile's stores.  Rows
     // outside the frame fall out of the buffer's range check (gfx950 checks voffset + soffset).
@@ -195,6 +202,7 @@ struct StageNHWC16 {
     }
     // y0 >= R only (every tile but the first of the frame): offsets stay non-negative
     __device__ __forceinline__ void load(const ConvArgs &a, int n_img, int x0, int y0, int tid) {
+        set_interior(a, x0, y0);
         const int soff = (y0 - R) * row_bytes;
         const int lo = R - y0, hi = a.H + R - y0;          // valid tile rows: lo <= ty < hi
 #pragma unroll
@@ -205,6 +213,7 @@ struct StageNHWC16 {
     }
     // any y0 (prologue of a chunk): per-lane offsets, rows above the frame pushed out of range
     __device__ __forceinline__ void load_first(const ConvArgs &a, int n_img, int x0, int y0, int tid) {
+        set_interior(a, x0, y0);
         const int lo = R - y0, hi = a.H + R - y0;
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
@@ -212,13 +221,19 @@ struct StageNHWC16 {
             v[it] = __builtin_amdgcn_raw_buffer_load_b128(rs, ok[it] ? voff[it] + (y0 - R) * row_bytes : (int)0x80000000, 0, 0);
         }
     }
+    // interior tiles (most of a frame) skip the per-pixel pad select: 8 of the ~10 vector instructions of an iteration
     __device__ __forceinline__ void store(int4 *tile, const ConvArgs &a, int tid) const {
+        if (interior) store_t<false>(tile, a, tid);
+        else store_t<true>(tile, a, tid);
+    }
+    template <bool PADSEL>
+    __device__ __forceinline__ void store_t(int4 *tile, const ConvArgs &a, int tid) const {
         const unsigned pw = (unsigned)a.pad_word;
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
             const int i = tid + it * 256;
             const v4u pad = {pw, pw, pw, pw};
-            const v4u t = ok[it] ? v[it] : pad;
+            const v4u t = (!PADSEL || ok[it]) ? v[it] : pad;
             if constexpr (CP > 0) {
                 int *tw = reinterpret_cast<int *>(tile);
                 const int row = i / SW, col = i - row * SW;
@@ -412,6 +427,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SESRQ_H5_WA
         AR[0] = ld_frag(a.afrag2 + 4 + (0 * 4 + a.risky_pe) * 64 + l);
         AR[1] = ld_frag(a.afrag2 + 4 + (1 * 4 + a.risky_pe) * 64 + l);
     }
+    // lane-constant byte offsets of the four pixel pairs inside a tile, computed ONCE (pinned: hipcc re-derived them -- 8 v_mul_lo
+    // + a dozen adds -- at the top of every tile)
+    unsigned pboff[2][2];
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            pboff[c][q] = GENERAL ? (unsigned)(((16 * w + n + pcol[c][q]) * CS + prow[c][q]) * 4) : 0u;
+            asm volatile("" : "+v"(pboff[c][q]));
+        }
     auto compute = [&](const int4 *tile, int y0) __attribute__((always_inline)) {
         RowIO io;
         if constexpr (EPI != EPI_LAST) io = make_rowio(a, n_img, y0, gx, g);
@@ -467,7 +492,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SESRQ_H5_WA
 #pragma unroll
             for (int c = 0; c < 2; ++c)
 #pragma unroll
-                for (int q = 0; q < 2; ++q) pb[c][q] = tb + ((16 * w + n + pcol[c][q]) * CS + prow[c][q]) * 4;
+                for (int q = 0; q < 2; ++q) pb[c][q] = tb + pboff[c][q];
 #pragma unroll
             for (int y4 = 0; y4 < MTH; y4 += 4) {
                 int s4[4][4];
