@@ -228,8 +228,8 @@ def main():
             cpu = {"reference_sim_py": {"value": 0.106, "unit": "frames/s", "cores": 8, "workload": "SESR-x4 1x1x1080x1920 through the reference's own "
                                         "sim.py path, dump flags off", "where": "survey container (SURVEY.md 6): the reference cannot travel to the GPU box, not re-run here"},
                    "value": round(1.0 / dt, 4), "unit": "frames/s", "cores": thr, "kind": "port",
-                   "sample": f"1 frame {H}x{W} of the same workload through oracle/sesrq_oracle.c (OpenMP, {thr} threads), {dt:.2f} s "
-                             "(the same run is the parity reference)"}
+                   "sample": f"1 frame {H}x{W} of the same workload through oracle/sesrq_oracle.c (OpenMP, {thr} threads), {dt:.2f} s wall "
+                             f"= {dt * thr:.0f} core-seconds of CPU work (the same run is the parity reference)"}
 
         # 200 forwards with an event pair around every launch (~20 ms): enough samples for the per-launch averages whatever
         # --steps is, and the device is at its working clock when the timed blocks start right after
