@@ -401,6 +401,25 @@ int sesrq_create(const sesrq_net_desc *d, const sesrq_options *opts, sesrq_net *
         net->quad_ok = L == 5 && net->trio_len[1] == 3 && !net->rc_separate && l0.mfma_kind == MFMA_F5 && l0.oc == 16 && d->layers[0].relu &&
                        (!l0.general || hyb0);
     }
+    {   // Residual merge (myQL/quan_func.py:256-270): q4 = clamp8(rint(fl(fl(u * M_res) * 2^-n_res + zero[L-1]))) is a function of the
+        // 9-bit integer u = rc + ic + 256 alone: a 511-entry byte table replaces the second requant of the fused trio's last phase
+        // (2 fma + add + cvt per value) by one LDS byte read.  Same fp32 operations, same order, as requant4<true> + round_pack.
+        unsigned char lut[512];
+        const float Mres = (float)d->M_res, shres = ldexpf(1.0f, -(int)d->n_res), zm = (float)d->zero[L - 1];
+        for (int u = 0; u < 512; ++u) {
+            const float prod = (float)u * Mres;              // one rounding of the exact product, as fma(MAGIC + u, M, -MAGIC * M)
+            float v = prod * shres;                          // exact (power of two)
+            v = v + zm;                                      // one rounding, as fma(prod, 2^-n, z)
+            v = fminf(fmaxf(v, -128.f), 127.f);
+            lut[u] = (unsigned char)(signed char)(int)nearbyintf(v);
+        }
+        if (hipMalloc((void **)&net->d_merge_lut, sizeof(lut)) != hipSuccess ||
+            hipMemcpy(net->d_merge_lut, lut, sizeof(lut), hipMemcpyHostToDevice) != hipSuccess) {
+            set_error("sesrq_create: device upload failed");
+            sesrq_destroy(net);
+            return 1;
+        }
+    }
     net->fd_proof = prove_fastdiv(d->scale_in, d->zero[0]);
     net->fd = net->fd_proof;
     if (net->div_mode == 1) net->fd.ok = 0;
@@ -419,6 +438,7 @@ int sesrq_create(const sesrq_net_desc *d, const sesrq_options *opts, sesrq_net *
 
 void sesrq_destroy(sesrq_net *net) {
     if (!net) return;
+    if (net->d_merge_lut) (void)hipFree(net->d_merge_lut);
     for (auto &lp : net->layers) {
         if (lp.d_wpk_general) (void)hipFree(lp.d_wpk_general);
         if (lp.d_wpk_merged) (void)hipFree(lp.d_wpk_merged);
@@ -546,6 +566,7 @@ static int forward_impl(const sesrq_net *net, const void *in, int in_dtype, void
             memset(&t, 0, sizeof(t));
             void *dst = (cur == bufA) ? bufB : bufA;
             t.in = cur; t.out = dst; t.rc_in = bufRC;
+            t.merge_lut = net->d_merge_lut;
             t.N = N; t.H = H; t.W = W;
             t.wg_budget = net->wg_budget;
             t.pad_in = lp.base.pad_word;

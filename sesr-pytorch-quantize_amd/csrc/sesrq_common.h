@@ -170,6 +170,7 @@ struct TrioArgs {
     int wg_budget;           // workgroup slots the launch may fill (0 = one round of the chip)
     int pad_in;              // pad word of the first layer's input
     float Mres, shres, z_merge;
+    const int *merge_lut;    // 128 dwords = 512 bytes: q4 as a function of u = (rc + 128) + (ic + 128), the residual merge's second requant (sesrq_create)
     TrioLayer l[3];
 };
 
@@ -234,6 +235,7 @@ struct sesrq_net {
     int wg_budget = 0;
     float i8_in_scale = 0.f;            // > 0: int8 input frames are in this (scale, zero) domain of an upstream net
     int i8_in_zero = 0;
+    int *d_merge_lut = nullptr;         // device: 512-byte table of the residual merge (see TrioArgs::merge_lut)
     std::vector<int> trio_len;          // trio_len[k] == 3: layers k..k+2 are eligible for the fused hidden trio
     bool quad_ok = false;               // layers 0..3 eligible for the fused front (first layer + residual-merging trio)
     int device = 0;

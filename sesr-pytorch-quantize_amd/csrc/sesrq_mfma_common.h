@@ -185,6 +185,24 @@ __device__ __forceinline__ unsigned epi_preres(const int s[4], unsigned rcword, 
     return round_pack(w01, w23, -128.f, 127.f);
 }
 
+// The same with the second requant read out of the 512-byte table q4(u) that sesrq_create built (fused trio: table in LDS at byte
+// address lut_addr < 2^15).  The rounding constant also carries the table's address: c = ic + (MAGIC + 128 + lut_addr) is exact
+// (ulp 1), its low 16 bits are lut_addr + (ic + 128), and adding the rc byte to them (one v_add_u32_sdwa: WORD_0 + BYTE_k) IS the
+// LDS address of q4(u): per value 2 fma + med3 + add + sdwa-add + one ds_read_u8 (+ 3/4 perm), no second requant.
+template <bool BIASED, class AT>
+__device__ __forceinline__ unsigned epi_preres_lut(const int s[4], unsigned rcword, const AT &a, float lut_magic) {
+    typedef const unsigned char __attribute__((address_space(3))) *lds_u8_t;
+    v2f v01, v23;
+    requant4<BIASED>(s, a.Mf, a.sh, -128.f, v01, v23);
+    const unsigned rcx = rcword ^ 0x80808080u;                 // rc + 128 as unsigned bytes
+    const v2f mg = {lut_magic, lut_magic};                     // MAGIC + 128 + lut_addr
+    v2f c01 = {med3(v01[0], -128.f, 127.f), med3(v01[1], -128.f, 127.f)}, c23 = {med3(v23[0], -128.f, 127.f), med3(v23[1], -128.f, 127.f)};
+    c01 = c01 + mg; c23 = c23 + mg;
+    const unsigned a0 = (fbits(c01[0]) & 0xffffu) + (rcx & 0xffu), a1 = (fbits(c01[1]) & 0xffffu) + ((rcx >> 8) & 0xffu);
+    const unsigned a2 = (fbits(c23[0]) & 0xffffu) + ((rcx >> 16) & 0xffu), a3 = (fbits(c23[1]) & 0xffffu) + (rcx >> 24);
+    return pack_lo_bytes(*(lds_u8_t)(size_t)a0, *(lds_u8_t)(size_t)a1, *(lds_u8_t)(size_t)a2, *(lds_u8_t)(size_t)a3);
+}
+
 // PE clamp / sum / adder clamp / add constant               (myQL/quan_func.py:370,380-386,437,491)
 // NV: real rows of the lane (the last layer's three-row map leaves s[3] untouched: padding, never read)
 template <int MODE, int NV = 4, class AT>

@@ -23,6 +23,9 @@
 #include <mutex>
 #include <type_traits>
 
+#ifndef SESRQ_TRIO_LUT
+#define SESRQ_TRIO_LUT 1        /* A/B knob: 0 = the residual merge's second requant in arithmetic instead of the LDS table */
+#endif
 #ifndef SESRQ_TRIO_NOPAD
 #define SESRQ_TRIO_NOPAD 1      /* A/B knob: 0 = the inner phases always run their per-row pad select */
 #endif
@@ -37,7 +40,8 @@ constexpr int TP = 66;            // LDS row pitch (pixels): computed columns -1
 constexpr int TR = TH + 2;        // rows per LDS window
 constexpr int OOB = (int)0x80000000;
 constexpr int TRIO_WIN = TR * TP + 2;      // pixels per LDS window (+ 2: lane group 3 over-reads one pixel)
-constexpr int TRIO_LDS_BYTES = 3 * TRIO_WIN * 16;
+constexpr int TRIO_LUT_I4 = 32;               // 512-byte table of the residual merge behind the three windows
+constexpr int TRIO_LDS_BYTES = (3 * TRIO_WIN + TRIO_LUT_I4) * 16;
 
 struct TrioStage {
     static constexpr int NIT = 3;         // 660 pixels (cold: 10 rows) or 528 (steady: 8 rows) over 256 threads
@@ -99,6 +103,9 @@ template <int EPI_C, bool U8>
 __global__ __launch_bounds__(256) void mfma_trio_kernel(const TrioArgs a) {
     extern __shared__ int4 trio_lds[];             // dynamic: the launch pads the size so that exactly `occ` workgroups fit a CU
     int4 *bufI = trio_lds, *bufA = trio_lds + TRIO_WIN, *bufB = trio_lds + 2 * TRIO_WIN;
+    constexpr bool LUT = EPI_C == EPI_PRERES && SESRQ_TRIO_LUT;
+    // MAGIC + 128 + the table's LDS byte address (exact: < 2^24); see epi_preres_lut
+    const float lut_magic = MAGIC + 128.f + (float)(unsigned)(size_t)(const __attribute__((address_space(3))) void *)(trio_lds + 3 * TRIO_WIN);
     const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, n = l & 15, g = l >> 4;
     const int n_img = blockIdx.z;
     const int x0 = blockIdx.x * TV - 2;              // frame column of computed column 0
@@ -111,6 +118,9 @@ __global__ __launch_bounds__(256) void mfma_trio_kernel(const TrioArgs a) {
     const int y_begin = a.run_unit * (int)(((long long)blockIdx.y * units_total) / gridDim.y);
     const int y_end = a.run_unit * (int)(((long long)(blockIdx.y + 1) * units_total) / gridDim.y);
     if (y_begin >= y_end) return;
+    if constexpr (LUT) {           // visible to every wave long before the first residual merge (barriers of the cold start)
+        if (threadIdx.x < 128) reinterpret_cast<int *>(trio_lds + 3 * TRIO_WIN)[threadIdx.x] = a.merge_lut[threadIdx.x];
+    }
 
     const int c = 16 * w + n, gx = x0 + c;
     const bool col_in = (gx >= 0) & (gx < a.W);                   // inner layers: inside the frame, else pad
@@ -189,7 +199,16 @@ __global__ __launch_bounds__(256) void mfma_trio_kernel(const TrioArgs a) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) s4[r][i] = acc[i];
             }
-            emit_rows4<EPI_C, false, true, U8>(s4, ec, io, y4, a.l[2].zlo);
+            if constexpr (LUT) {
+                const v4u rv = __builtin_amdgcn_raw_buffer_load_b128(io.rc_in, io.voff, y4 * io.row_bytes, 0);
+                unsigned rcw[4] = {rv[0], rv[1], rv[2], rv[3]}, wq[4];
+                transpose4(rcw);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) wq[r] = epi_preres_lut<true>(s4[r], rcw[r], ec, lut_magic);
+                store_rows4(io.out, io, y4, wq);
+            } else {
+                emit_rows4<EPI_C, false, true, U8>(s4, ec, io, y4, a.l[2].zlo);
+            }
         }
     };
     using std::integral_constant;
