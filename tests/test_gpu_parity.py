@@ -602,6 +602,34 @@ def test_forward_is_deterministic_at_full_size(hard):
         assert torch.equal(q0, q2)
 
 
+@pytest.mark.parametrize("hard", [False, True], ids=["merged", "general"])
+@pytest.mark.parametrize("oc_last,ps", [(12, 1), (8, 2), (9, 3), (5, 1), (7, 1), (11, 1), (12, 2), (13, 1), (16, 2)])
+def test_last_layer_channel_counts(oc_last, ps, hard):
+    """Every way the last MFMA layer lays out its output rows (last_slot_oc): up to 12 channels -> three real rows per lane group
+    (generic map, 1-byte stores; the 12 x PixelShuffle(2) pair map), more -> four; merged and per-PE kernels, int8-only (the
+    compile-time store flavours) and int8 + fp32 outputs, against the C oracle."""
+    from oracle import c_oracle as CO
+    net = O.synth_net("sesr_x2", 300 + oc_last + 16 * ps, hard=hard)
+    rng = np.random.default_rng(oc_last * 7 + ps)
+    last = net.layers[-1]
+    if hard:
+        w = rng.choice(np.array([-128, -100, 90, 127], dtype=np.int64), size=(oc_last, 16, 5, 5))
+    else:
+        w = np.clip(np.rint(rng.standard_normal((oc_last, 16, 5, 5)) * 14.0), -128, 127)
+    net.layers[-1] = O.Layer(wq=w.astype(np.int8), add_const=rng.integers(-6000, 6000, oc_last).astype(np.int32), M=last.M, n=last.n, relu=False)
+    net.pixel_shuffle = ps
+    e = sesrq.Engine(bundle_from_oracle(net), _dev())
+    assert e.layer_engines()[-1].startswith("mfma-h5-"), e.layer_engines()
+    x = rand_frame((2, 3, 21, 70), oc_last + ps)
+    want = CO.forward(net, x)
+    xt = torch.from_numpy(x).to(_dev())
+    q, y = e.forward(xt)
+    _cmp("q (int8 + fp32 outputs)", q, want["q_out"])
+    _cmp("y", y, want["y"])
+    q2, _ = e.forward(xt, want_f=False)
+    _cmp("q (int8 only)", q2, want["q_out"])
+
+
 def test_empty_and_degenerate_inputs():
     net = O.synth_net("nrdm", 1)
     e = sesrq.Engine(bundle_from_oracle(net), _dev())
