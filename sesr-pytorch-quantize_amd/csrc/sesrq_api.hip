@@ -52,14 +52,16 @@ static void pack_weights(const sesrq_layer_desc &d, int ocp, bool first, std::ve
 // Load-time proof that the 18-bit PE clamp and the 20-bit adder clamp can never fire:
 // for q in [-128,127] (pad value included) the extreme PE sums are 127*S+ + 128*S- and
 // -(128*S+ + 127*S-).  (myQL/quan_func.py:358-370,437 are then identities.)
+// risky_oc (optional): bit o = some PE sum of output channel o can leave the accumulator range
 static bool saturation_free(const sesrq_layer_desc &d, int zc, int acc_bits, int add_bits, long long &worst_pe,
-                            long long &worst_sum, int &risky_mask) {
+                            long long &worst_sum, int &risky_mask, int *risky_oc = nullptr) {
     risky_mask = 0;
+    if (risky_oc) *risky_oc = 0;
     const int taps = d.k * d.k;
     const long long acc_hi = (1LL << (acc_bits - 1)) - 1, add_hi = (1LL << (add_bits - 1)) - 1;
     worst_pe = worst_sum = 0;
     bool ok = (zc >= -128 && zc <= 127);
-    if (!ok) risky_mask = 15;
+    if (!ok) { risky_mask = 15; if (risky_oc) *risky_oc = 0xffff; }
     for (int o = 0; o < d.oc; ++o) {
         long long tot_hi = 0, tot_lo = 0;
         for (int p = 0; p < 4; ++p) {
@@ -71,7 +73,7 @@ static bool saturation_free(const sesrq_layer_desc &d, int zc, int acc_bits, int
                 }
             const long long hi = 127 * sp + 128 * sn, lo = 128 * sp + 127 * sn;
             worst_pe = std::max(worst_pe, std::max(hi, lo));
-            if (hi > acc_hi || lo > acc_hi + 1) { ok = false; risky_mask |= 1 << p; }
+            if (hi > acc_hi || lo > acc_hi + 1) { ok = false; risky_mask |= 1 << p; if (risky_oc) *risky_oc |= 1 << o; }
             tot_hi += hi; tot_lo += lo;
         }
         worst_sum = std::max(worst_sum, std::max(tot_hi, tot_lo));
@@ -303,7 +305,7 @@ int sesrq_create(const sesrq_net_desc *d, const sesrq_options *opts, sesrq_net *
         lp.k = l.k; lp.ic = l.ic; lp.oc = l.oc;
         lp.ocp = (k == L - 1) ? ((l.oc + 3) & ~3) : 16;
         const int zc = std::max(d->zero[k], -128);
-        lp.general = !saturation_free(l, zc, d->pe_acc_bits, d->pe_add_bits, lp.worst_pe, lp.worst_sum, lp.risky_mask);
+        lp.general = !saturation_free(l, zc, d->pe_acc_bits, d->pe_add_bits, lp.worst_pe, lp.worst_sum, lp.risky_mask, &lp.risky_oc);
         std::vector<int> gen, mer;
         pack_weights(l, lp.ocp, k == 0, gen, mer);
         const size_t bytes = gen.size() * sizeof(int);
@@ -626,7 +628,14 @@ static int forward_impl(const sesrq_net *net, const void *in, int in_dtype, void
             a.afrag = eff.general ? lp.d_afrag_general : lp.d_afrag_merged;
             // exactly one PE can saturate (and nothing forces the full per-PE path): merged chain + that PE's chain
             const bool one_pe = lp.general && !net->force_general && !dbg && lp.d_afrag_others && net->acc_bits == 18 && net->add_bits == 20;
-            if (one_pe) { a.afrag = lp.d_afrag_others; a.afrag2 = lp.d_afrag_general; a.risky_pe = __builtin_ctz(lp.risky_mask); a.afrag_sp = lp.d_afrag_sparse; }
+            if (one_pe) {
+                a.afrag = lp.d_afrag_others; a.afrag2 = lp.d_afrag_general; a.risky_pe = __builtin_ctz(lp.risky_mask); a.afrag_sp = lp.d_afrag_sparse;
+                // hidden-layer rows: channel o sits in register o >> 2 of lane group o & 3.  If every channel that can saturate lives in
+                // ONE register, the hybrid first layer clamps that register only (risky_reg), else all four (4)
+                a.risky_reg = 4;
+                for (int i = 0; i < 4; ++i)
+                    if (lp.risky_oc && (lp.risky_oc & ~(0xf << (4 * i))) == 0) a.risky_reg = i;
+            }
             if (lp.d_afrag_pesplit) a.afrag = lp.d_afrag_pesplit;
             if (launch_mfma(lp, a, src, epi, eff.general, st, one_pe, tap_mfma)) return 1;
         } else if (launch_dot4(eff, a, src, epi, st)) return 1;

@@ -130,6 +130,7 @@ struct ConvArgs {
     const int4 *afrag_sp;    // first layer, hybrid, 3 channels: 2:4-sparse images [4 header][others: 64 lanes][risky PE: 64 lanes] (pack_f5_sparse) or NULL
     const int4 *afrag2;      // mfma hybrid mode: afrag = merged image WITHOUT the risky PE, afrag2 = per-PE (general) image; risky_pe selects its chain
     int risky_pe;
+    int risky_reg;           // hybrid first layer: the one accumulator register (0..3) that holds every channel that can saturate, or 4 = any
     int *dbg_pe;             // (N,4,OC,H,W) int32 or NULL
     int *dbg_add;            // (N,OC,H,W) int32 or NULL
     signed char *dbg_q0;     // (N,IC,H,W) int8: quantised input of layer 0 or NULL (dot4 kernels only)
@@ -204,6 +205,7 @@ struct LayerPlan {
     // static saturation analysis (per layer)
     long long worst_pe = 0, worst_sum = 0;
     int risky_mask = 0;      // PEs (bit p) whose 18-bit clamp can fire for some output channel
+    int risky_oc = 0;        // output channels (bit o) with such a PE sum
 };
 
 void set_error(const std::string &msg);

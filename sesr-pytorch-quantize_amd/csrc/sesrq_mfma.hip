@@ -707,7 +707,8 @@ constexpr int F5_SH = F5_TH + 4;
 constexpr int F5_SWP = MTW + 8;         // staged pixel columns (2 halo + 64 + 2 halo + over-read)
 constexpr int F5_PITCH = F5_SH + 2;     // LDS column pitch in dwords (>= rows, = 2 mod 4)
 static_assert(F5_PITCH % 4 == 2 && 3 * F5_PITCH + F5_SH < 256, "column pitch: bank rule / ds_read2_b32 offset range");
-template <int MODE, int SRC, bool RC, int NCH>
+// RR (HYBS): the accumulator register whose rows can saturate (sesrq_api.hip: risky_reg), 4 = clamp all four
+template <int MODE, int SRC, bool RC, int NCH, int RR = 4>
 __device__ __forceinline__ void mfma_f5_body(const ConvArgs &a, int4 *buf0, int4 *buf1) {
     constexpr bool GENERAL = mode_general(MODE);
     constexpr int SH = F5_SH, SWP = F5_SWP, PITCH = F5_PITCH;
@@ -790,7 +791,8 @@ __device__ __forceinline__ void mfma_f5_body(const ConvArgs &a, int4 *buf0, int4
                         const v8i B8 = {B0[0], B0[1], B0[2], B0[3], B1[0], B1[1], B1[2], B1[3]};
                         v4i rk = smfmac(AR[0], B8, acc0, idx_r);
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) rk[i] = med3_biased(rk[i], rlo[i], rhi[i]);
+                        for (int i = 0; i < 4; ++i)
+                            if (RR == 4 || RR == i) rk[i] = med3_biased(rk[i], rlo[i], rhi[i]);
                         acc[0] = smfmac(A[0][0], B8, rk, idx_o);
                     } else if constexpr (MODE == HYB) {       // same B operands, A masked to the risky PE's channel
                         v4i rk = mfma(AR[0], B0, acc0);
@@ -822,13 +824,13 @@ __device__ __forceinline__ void mfma_f5_body(const ConvArgs &a, int4 *buf0, int4
 // NOT for the per-PE (general) variants: squeezed to 128 VGPRs, hipcc 7.2 produced a GEN_STD + residual-tensor instance whose
 // first output word was garbage in lanes 28..31 (caught by the satw_zeros golden vectors; the same source without the
 // attribute, or with unrelated extra code in the loop, is correct) -- those take the registers they ask for.
-template <int MODE, int SRC, bool RC, int NCH>
+template <int MODE, int SRC, bool RC, int NCH, int RR = 4>
 #ifndef SESRQ_F5_WAVES
 #define SESRQ_F5_WAVES 4
 #endif
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SESRQ_F5_WAVES))) void mfma_f5_kernel_w4(const ConvArgs a) {
     __shared__ int4 buf0[(F5_SWP * F5_PITCH + 3) / 4], buf1[(F5_SWP * F5_PITCH + 3) / 4];      // SH rows of 4-byte pixels
-    mfma_f5_body<MODE, SRC, RC, NCH>(a, buf0, buf1);
+    mfma_f5_body<MODE, SRC, RC, NCH, RR>(a, buf0, buf1);
 }
 template <int MODE, int SRC, bool RC, int NCH>
 __global__ __launch_bounds__(256) void mfma_f5_kernel(const ConvArgs a) {
@@ -868,6 +870,22 @@ static void launch(K kern, ConvArgs a, hipStream_t st, int tile_h = MTH) {
     a.chunk_tiles = (int)((row_tiles + k - 1) / k);
     dim3 grid(strips, (int)k, a.N);
     launch_kernel(kern, grid, dim3(256), 0, st, a);
+}
+
+// hybrid first layer on the sparse MFMA, by the register that needs the clamp (3 input channels only: a.afrag_sp is set for nothing else)
+template <int SRC, bool RC, int NCH>
+static void launch_f5_sparse(const ConvArgs &a, hipStream_t st) {
+    if constexpr (NCH == 3) {
+        switch (a.risky_reg) {
+            case 0: launch(mfma_f5_kernel_w4<HYBS, SRC, RC, 3, 0>, a, st, F5_TH); break;
+            case 1: launch(mfma_f5_kernel_w4<HYBS, SRC, RC, 3, 1>, a, st, F5_TH); break;
+            case 2: launch(mfma_f5_kernel_w4<HYBS, SRC, RC, 3, 2>, a, st, F5_TH); break;
+            case 3: launch(mfma_f5_kernel_w4<HYBS, SRC, RC, 3, 3>, a, st, F5_TH); break;
+            default: launch(mfma_f5_kernel_w4<HYBS, SRC, RC, 3, 4>, a, st, F5_TH); break;
+        }
+    } else {
+        launch(mfma_f5_kernel_w4<HYB, SRC, RC, NCH>, a, st, F5_TH);
+    }
 }
 
 #define SESRQ_BY_MODE(KERN, ...)                                                         \
@@ -939,7 +957,7 @@ int launch_mfma(const LayerPlan &lp, const ConvArgs &a_in, int src, int epi, boo
 #define SESRQ_F5(...)                                                                    \
     do {                                                                                 \
         if (mode == MERGED) launch(mfma_f5_kernel_w4<MERGED, __VA_ARGS__>, a, st, F5_TH);       \
-        else if (mode == HYB && a.afrag_sp && SESRQ_F5_SPARSE) launch(mfma_f5_kernel_w4<HYBS, __VA_ARGS__>, a, st, F5_TH);        \
+        else if (mode == HYB && a.afrag_sp && SESRQ_F5_SPARSE) launch_f5_sparse<__VA_ARGS__>(a, st);        \
         else if (mode == HYB) launch(mfma_f5_kernel_w4<HYB, __VA_ARGS__>, a, st, F5_TH);        \
         else if (mode == GEN_STD) launch(mfma_f5_kernel<GEN_STD, __VA_ARGS__>, a, st, F5_TH);   \
         else launch(mfma_f5_kernel<GEN_ANY, __VA_ARGS__>, a, st, F5_TH);                        \

@@ -186,21 +186,25 @@ __device__ __forceinline__ unsigned epi_preres(const int s[4], unsigned rcword, 
 }
 
 // The same with the second requant read out of the 512-byte table q4(u) that sesrq_create built (fused trio: table in LDS at byte
-// address lut_addr < 2^15).  The rounding constant also carries the table's address: c = ic + (MAGIC + 128 + lut_addr) is exact
-// (ulp 1), its low 16 bits are lut_addr + (ic + 128), and adding the rc byte to them (one v_add_u32_sdwa: WORD_0 + BYTE_k) IS the
-// LDS address of q4(u): per value 2 fma + med3 + add + sdwa-add + one ds_read_u8 (+ 3/4 perm), no second requant.
+// address lut_addr < 2^15).  The rounding constant also carries the table's address: c = ic + (MAGIC + 256 + lut_addr) is exact
+// (ulp 1), its low 16 bits are lut_addr + (ic + 256), and adding the signed rc byte to them (one v_add_u32_sdwa) IS the LDS address
+// of q4(u): per value 2 fma + med3 + add + sdwa-add + one byte read (+ 1/4 v_lshl_or), no second requant, no byte shuffles.
 template <bool BIASED, class AT>
 __device__ __forceinline__ unsigned epi_preres_lut(const int s[4], unsigned rcword, const AT &a, float lut_magic) {
     typedef const unsigned char __attribute__((address_space(3))) *lds_u8_t;
     v2f v01, v23;
     requant4<BIASED>(s, a.Mf, a.sh, -128.f, v01, v23);
-    const unsigned rcx = rcword ^ 0x80808080u;                 // rc + 128 as unsigned bytes
-    const v2f mg = {lut_magic, lut_magic};                     // MAGIC + 128 + lut_addr
+    const v2f mg = {lut_magic, lut_magic};                     // MAGIC + 256 + lut_addr: the low 16 bits of c are lut_addr + (ic + 256)
     v2f c01 = {med3(v01[0], -128.f, 127.f), med3(v01[1], -128.f, 127.f)}, c23 = {med3(v23[0], -128.f, 127.f), med3(v23[1], -128.f, 127.f)};
     c01 = c01 + mg; c23 = c23 + mg;
-    const unsigned a0 = (fbits(c01[0]) & 0xffffu) + (rcx & 0xffu), a1 = (fbits(c01[1]) & 0xffffu) + ((rcx >> 8) & 0xffu);
-    const unsigned a2 = (fbits(c23[0]) & 0xffffu) + ((rcx >> 16) & 0xffu), a3 = (fbits(c23[1]) & 0xffffu) + (rcx >> 24);
-    return pack_lo_bytes(*(lds_u8_t)(size_t)a0, *(lds_u8_t)(size_t)a1, *(lds_u8_t)(size_t)a2, *(lds_u8_t)(size_t)a3);
+    // + the SIGNED rc byte (v_add_u32_sdwa, WORD_0 + sign-extended BYTE_k): lut_addr + (rc + ic + 256) = the address of q4(u)
+    const unsigned a0 = (fbits(c01[0]) & 0xffffu) + (unsigned)(int)(signed char)(rcword), a1 = (fbits(c01[1]) & 0xffffu) + (unsigned)(int)(signed char)(rcword >> 8);
+    const unsigned a2 = (fbits(c23[0]) & 0xffffu) + (unsigned)(int)(signed char)(rcword >> 16), a3 = (fbits(c23[1]) & 0xffffu) + (unsigned)((int)rcword >> 24);
+    // bytes 0 / 2 and 1 / 3 land in the low / high halves of two registers (ds_read_u8_d16 / _d16_hi), one v_lshl_or joins them
+    typedef unsigned short v2us __attribute__((ext_vector_type(2)));
+    const v2us x = {(unsigned short)*(lds_u8_t)(size_t)a0, (unsigned short)*(lds_u8_t)(size_t)a2};
+    const v2us y = {(unsigned short)*(lds_u8_t)(size_t)a1, (unsigned short)*(lds_u8_t)(size_t)a3};
+    return __builtin_bit_cast(unsigned, x) | (__builtin_bit_cast(unsigned, y) << 8);
 }
 
 // PE clamp / sum / adder clamp / add constant               (myQL/quan_func.py:370,380-386,437,491)

@@ -104,8 +104,8 @@ __global__ __launch_bounds__(256) void mfma_trio_kernel(const TrioArgs a) {
     extern __shared__ int4 trio_lds[];             // dynamic: the launch pads the size so that exactly `occ` workgroups fit a CU
     int4 *bufI = trio_lds, *bufA = trio_lds + TRIO_WIN, *bufB = trio_lds + 2 * TRIO_WIN;
     constexpr bool LUT = EPI_C == EPI_PRERES && SESRQ_TRIO_LUT;
-    // MAGIC + 128 + the table's LDS byte address (exact: < 2^24); see epi_preres_lut
-    const float lut_magic = MAGIC + 128.f + (float)(unsigned)(size_t)(const __attribute__((address_space(3))) void *)(trio_lds + 3 * TRIO_WIN);
+    // MAGIC + 256 + the table's LDS byte address (exact: < 2^24); see epi_preres_lut
+    const float lut_magic = MAGIC + 256.f + (float)(unsigned)(size_t)(const __attribute__((address_space(3))) void *)(trio_lds + 3 * TRIO_WIN);
     const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, n = l & 15, g = l >> 4;
     const int n_img = blockIdx.z;
     const int x0 = blockIdx.x * TV - 2;              // frame column of computed column 0
