@@ -106,6 +106,29 @@ __global__ __launch_bounds__(256) void k(unsigned *out, int iters, float mf, flo
             asm volatile("v_smfmac_i32_16x16x128_i8 %0, %1, %2, %3" : "+v"(acc) : "v"(As), "v"(Bd), "v"(idx));
         }
         keep ^= (unsigned)acc[0];
+    } else if constexpr (KIND == 9) {                  // three dependent legacy K=32 MFMAs (gfx940 form, 8-byte operands): cycles per instruction?
+        v4i acc = {0, 0, 0, 0};
+        typedef int v2i __attribute__((ext_vector_type(2)));
+        const v2i A2 = {(int)threadIdx.x, 2}, B2 = {5, (int)threadIdx.x};
+        for (int i = 0; i < iters; ++i) {
+            asm volatile("v_mfma_i32_16x16x32_i8 %0, %1, %2, %0" : "+v"(acc) : "v"(A2), "v"(B2));
+            asm volatile("v_mfma_i32_16x16x32_i8 %0, %1, %2, %0" : "+v"(acc) : "v"(A2), "v"(B2));
+            asm volatile("v_mfma_i32_16x16x32_i8 %0, %1, %2, %0" : "+v"(acc) : "v"(A2), "v"(B2));
+        }
+        keep ^= (unsigned)acc[0];
+    } else if constexpr (KIND == 10) {                 // a16cvt with the third K-chunk (one tap of 9 = 16 of 64 bytes used) on the K=32 form
+        const v4i zero = {0, 0, 0, 0};
+        typedef int v2i __attribute__((ext_vector_type(2)));
+        const v2i A2 = {(int)threadIdx.x, 2}, B2 = {5, (int)threadIdx.x};
+        for (int i = 0; i < iters; ++i) {
+            v4i acc;
+            MFMA16(acc, zero) MFMA16A(acc)
+            asm volatile("v_mfma_i32_16x16x32_i8 %0, %1, %2, %0" : "+v"(acc) : "v"(A2), "v"(B2));
+            v2f p = {__builtin_bit_cast(float, acc[0]), __builtin_bit_cast(float, acc[1])}, q = {__builtin_bit_cast(float, acc[2]), __builtin_bit_cast(float, acc[3])};
+            unsigned w = 0;
+            EPI11(p, q, w)
+            keep ^= w;
+        }
     } else {                                            // b32 / b32cvt: 2 rows x 32 pixels = 4 a16 rows per iteration
         v16i zero;
         for (int j = 0; j < 16; ++j) zero[j] = 0;
@@ -151,7 +174,7 @@ int main() {
     unsigned *d; (void)hipMalloc(&d, 256 * 4 * 256 * 4);
     for (int rep = 0; rep < 2; ++rep) {
         run<0>("a16", d); run<1>("a16cvt", d); run<2>("a16pipe", d); run<3>("b32", d); run<4>("b32cvt", d);
-        run<5>("chain", d); run<6>("epi13", d); run<7>("a16indep", d); run<8>("smfmac128", d);
+        run<5>("chain", d); run<6>("epi13", d); run<7>("a16indep", d); run<8>("smfmac128", d); run<9>("k32x3", d); run<10>("a16cvt_k32", d);
     }
     return 0;
 }
