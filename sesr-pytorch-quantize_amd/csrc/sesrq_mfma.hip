@@ -296,6 +296,27 @@ struct StageNHWC16 {
         }                                                                                           \
     }
 
+// the same walk for a stage type whose following tiles take their top halo rows from the tile under computation (StageFrame)
+#define SESRQ_TILE_WALK_CARRY(TILE_H, STAGE_T, BUF0, BUF1, COMPUTE)                                          \
+    {                                                                                               \
+        const int row_tiles_ = (a.H + (TILE_H) - 1) / (TILE_H);                                      \
+        const int t_begin = (int)(((long long)blockIdx.y * row_tiles_) / gridDim.y);                \
+        const int t_end = (int)(((long long)(blockIdx.y + 1) * row_tiles_) / gridDim.y);            \
+        STAGE_T st;                                                                                 \
+        st.init(a, n_img, x0, tid);                                                                 \
+        st.load_first(a, n_img, x0, t_begin * (TILE_H), tid);                                       \
+        st.store(BUF0, a, tid);                                                                     \
+        __syncthreads();                                                                            \
+        for (int t = t_begin; t < t_end; ++t) {                                                     \
+            const int y0 = t * (TILE_H);                                                            \
+            const bool cur0 = ((t - t_begin) & 1) == 0;                                             \
+            if (t + 1 < t_end) st.load(a, n_img, x0, y0 + (TILE_H), tid);                           \
+            { const int4 *cur_tile = cur0 ? BUF0 : BUF1; COMPUTE(cur_tile) }                        \
+            if (t + 1 < t_end) { if (cur0) st.store_next(BUF1, BUF0, a, tid); else st.store_next(BUF0, BUF1, a, tid); }  \
+            __syncthreads();                                                                        \
+        }                                                                                           \
+    }
+
 // ------------------------------------------------------------------ hidden 3x3, 16 -> 16 channels
 template <int MODE, int EPI>
 __global__ __launch_bounds__(256) void mfma_h3_kernel(const ConvArgs a) {
@@ -623,6 +644,9 @@ __global__ __launch_bounds__(256) void mfma_h5p_kernel(const ConvArgs a) {
 // distinct even banks and the two lane groups of a 32-lane half an odd number of rows apart, i.e. on the odd banks.
 // NCH: input channels as a compile-time count (1 and 3 are the reference's nets), or 4 = "a.ic of them, tested per channel":
 // the wave-uniform test put every channel's load and quantise code into a block of its own.
+#ifndef SESRQ_F5_CARRY
+#define SESRQ_F5_CARRY 1      /* A/B knob: 0 = every tile of a run stages (loads + quantises) its whole window, halo rows included */
+#endif
 template <int SRC, int SH, int SWP, int PITCH, int NCH>
 struct StageFrame {
     __device__ __forceinline__ static bool has_channel(const ConvArgs &a, int c) { return NCH < 4 ? c < NCH : c < a.ic; }
@@ -649,14 +673,21 @@ struct StageFrame {
             if (!okx) ty[it] = -(1 << 20);
         }
     }
+    // Tiles of a run are stacked: the top CARRY = SH - TH rows of the next tile's staged window are the bottom CARRY rows of this
+    // one's.  They are copied inside the LDS (store_next) instead of being loaded and quantised again: a following tile stages
+    // only its TH new rows (element i -> row CARRY + i / SWP, same column), 864 pixels instead of 1152.
+    static constexpr int CARRY = SESRQ_F5_CARRY ? 4 : 0;
+    static constexpr int NITN = ((SH - CARRY) * SWP + 255) / 256;
     template <bool FIRST>
     __device__ __forceinline__ void load_t(const ConvArgs &a, int y0) {
-        const int soff = (y0 - 2) * row_bytes;             // FIRST: may be negative -> folded into the lane offset
-        const int lo = 2 - y0, hi = a.H + 2 - y0;
+        constexpr int R0 = FIRST ? 0 : CARRY, N = FIRST ? NIT : NITN;
+        const int soff = (y0 - 2 + R0) * row_bytes;        // FIRST: may be negative -> folded into the lane offset
+        const int lo = 2 - y0 - R0, hi = a.H + 2 - y0 - R0;
 #pragma unroll
-        for (int it = 0; it < NIT; ++it) {
+        for (int it = 0; it < N; ++it) {
             ok[it] = (ty[it] >= lo) & (ty[it] < hi);
-            const int vo = FIRST ? (ok[it] ? voff[it] + soff : (int)0x80000000) : voff[it];
+            int vo = FIRST ? (ok[it] ? voff[it] + soff : (int)0x80000000) : voff[it];
+            if (!FIRST && CARRY && (it + 1) * 256 > (SH - CARRY) * SWP && threadIdx.x + it * 256 >= (SH - CARRY) * SWP) vo = (int)0x80000000;
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 raw[it][c] = 0;
@@ -670,10 +701,12 @@ struct StageFrame {
     }
     __device__ __forceinline__ void load(const ConvArgs &a, int n_img, int x0, int y0, int tid) { load_t<false>(a, y0); }
     __device__ __forceinline__ void load_first(const ConvArgs &a, int n_img, int x0, int y0, int tid) { load_t<true>(a, y0); }
-    __device__ __forceinline__ void store(int4 *cp, const ConvArgs &a, int tid) const {
+    template <bool FIRST>
+    __device__ __forceinline__ void store_t(int4 *cp, const ConvArgs &a, int tid) const {
+        constexpr int R0 = FIRST ? 0 : CARRY, N = FIRST ? NIT : NITN;
         int *cpw = reinterpret_cast<int *>(cp);
 #pragma unroll
-        for (int it = 0; it < NIT; ++it) {
+        for (int it = 0; it < N; ++it) {
             const int i = tid + it * 256;
             unsigned b[4];
 #pragma unroll
@@ -688,8 +721,29 @@ struct StageFrame {
             }
             int word = (int)pack_lo_bytes(b[0], b[1], b[2], b[3]);
             if (!ok[it]) word = a.pad_word;
-            if (i < SH * SWP) cpw[(i % SWP) * PITCH + (i / SWP)] = word;      // column-major: dword [column][row], column pitch PITCH
+            if (i < (SH - R0) * SWP) cpw[(i % SWP) * PITCH + (i / SWP) + R0] = word;      // column-major: dword [column][row], column pitch PITCH
         }
+        // The last iteration's registers are loaded by the first tile only and are free afterwards; waves that skip that iteration
+        // (no lane of theirs has an element) never wait for those loads, the registers are re-used inside the compute loop, and
+        // hipcc's waitcnt pass then drains ALL loads in the loop's preheader -- the next tile's too, which are meant to fly during the
+        // compute (first layer +0.6 us).  Retire them here, once per run.
+        if constexpr (FIRST && CARRY > 0) __builtin_amdgcn_s_waitcnt(0x0f70);      // vmcnt(0)
+    }
+    __device__ __forceinline__ void store(int4 *cp, const ConvArgs &a, int tid) const { store_t<true>(cp, a, tid); }
+    // a following tile: rows SH-CARRY .. SH-1 of the tile under computation (cur, read-only by now) become rows 0 .. CARRY-1 of nxt
+    // (a column's rows are adjacent dwords: two 8-byte moves per column), then the new rows
+    __device__ __forceinline__ void store_next(int4 *nxt, const int4 *cur, const ConvArgs &a, int tid) const {
+        if constexpr (CARRY == 0) { store_t<true>(nxt, a, tid); return; }
+        static_assert(PITCH % 2 == 0 && (SH - 4) % 2 == 0 && 2 * SWP <= 256, "8-byte carry moves");
+#ifndef SESRQ_F5_CARRY_MODE
+#define SESRQ_F5_CARRY_MODE 1
+#endif
+        const int ct = SESRQ_F5_CARRY_MODE == 2 ? 255 - tid : tid;      // mode 2: the waves with one quantiser iteration less do the copy
+        const int cc = (ct >> 1) * PITCH + 2 * (ct & 1);      // the read is issued first, the quantiser's VALU work covers its latency
+        int2 v = {0, 0};
+        if (SESRQ_F5_CARRY_MODE != 3 && ct < 2 * SWP) v = *reinterpret_cast<const int2 *>(reinterpret_cast<const int *>(cur) + cc + (SH - 4));
+        store_t<false>(nxt, a, tid);
+        if (SESRQ_F5_CARRY_MODE != 3 && ct < 2 * SWP) *reinterpret_cast<int2 *>(reinterpret_cast<int *>(nxt) + cc) = v;
     }
 };
 
@@ -816,7 +870,8 @@ __device__ __forceinline__ void mfma_f5_body(const ConvArgs &a, int4 *buf0, int4
     };
 #define SESRQ_COMPUTE(B) compute(B, y0);
     using Stage = StageFrame<SRC, SH, SWP, PITCH, NCH>;
-    SESRQ_TILE_WALK_H(F5_TH, Stage, buf0, buf1, SESRQ_COMPUTE)
+    static_assert(F5_SH - F5_TH == 4, "StageFrame carries SH - TH = 4 rows");
+    SESRQ_TILE_WALK_CARRY(F5_TH, Stage, buf0, buf1, SESRQ_COMPUTE)
 #undef SESRQ_COMPUTE
 }
 // 4 waves per SIMD for the merged / hybrid first layer: with the default heuristics hipcc takes 141-153 VGPRs here (3 waves);

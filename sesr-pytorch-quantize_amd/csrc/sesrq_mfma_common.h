@@ -63,10 +63,10 @@ __device__ __forceinline__ float quotient_in(float x, float s, const FastDiv &fd
     return __builtin_fmaf(__builtin_fmaf(-s, q, xc), fd.r2, q);
 }
 // input quantiser q0 = clamp8(rint(fl(fl(x/s) + z)))  (myQL/quan_func.py:225) as the low byte (two's complement) of the
-// returned word: clamp the un-rounded value, then round to nearest even by adding 1.5 * 2^23 (clamp and rint commute for
-// integer bounds) -- no v_rndne / v_cvt_i32
+// returned word: round to nearest even by adding 1.5 * 2^23 -- no v_rndne / v_cvt_i32 -- and NO clamp of the result: quotient_in
+// clamped x to [fd.xlo, fd.xhi], whose ends quantise to exactly -128 and 127 (sesrq_verify.hip proves the whole range, unclamped)
 __device__ __forceinline__ unsigned quantize_in_bits(float x, float s, float z, const FastDiv &fd) {
-    return __builtin_bit_cast(unsigned, __fadd_rn(med3(__fadd_rn(quotient_in(x, s, fd), z), -128.f, 127.f), 12582912.f));
+    return __builtin_bit_cast(unsigned, __fadd_rn(__fadd_rn(quotient_in(x, s, fd), z), 12582912.f));
 }
 
 // A wave-uniform float pinned to a VGPR.  hipcc 7.2 (clang 22) un-packs a v_pk_fma_f32 that sits in the shadow of an MFMA into two

@@ -180,7 +180,18 @@ __global__ __launch_bounds__(256) void mfma_trio_kernel(const TrioArgs a) {
         }
     };
     // outer layer: output rows Y .. Y+NR-1 (NR = 8, or 4 in a half step) from window positions 0 .. NR+1 of layer b
-    auto outer = [&](auto NRC, int Y) __attribute__((always_inline)) {
+    // The residual operand of output rows Y .. Y+NR-1 (one 16-byte load per 4 rows).  Issued a whole phase before its use: written
+    // next to the epilogue that consumes it, hipcc placed the load in front of the 4-row group and the s_waitcnt vmcnt(0) three
+    // MFMAs later (the transposing swaps are scheduled early) -- an L2 / MALL round trip in the open, twice per step.
+    auto rc_fetch = [&](auto NRC, int Y, v4u (&rcp)[2]) __attribute__((always_inline)) {
+        constexpr int NR = decltype(NRC)::value;
+        if constexpr (LUT) {
+            const int vo = col_out ? voff_c + Y * io.row_bytes : OOB;
+#pragma unroll
+            for (int y4 = 0; y4 < NR; y4 += 4) rcp[y4 / 4] = __builtin_amdgcn_raw_buffer_load_b128(io.rc_in, vo, y4 * io.row_bytes, 0);
+        }
+    };
+    auto outer = [&](auto NRC, int Y, const v4u (&rcp)[2]) __attribute__((always_inline)) {
         constexpr int NR = decltype(NRC)::value;
         const int4 *p = bufB + rdcol;
         io.voff = col_out ? voff_c + Y * io.row_bytes : OOB;
@@ -200,7 +211,7 @@ __global__ __launch_bounds__(256) void mfma_trio_kernel(const TrioArgs a) {
                 for (int i = 0; i < 4; ++i) s4[r][i] = acc[i];
             }
             if constexpr (LUT) {
-                const v4u rv = __builtin_amdgcn_raw_buffer_load_b128(io.rc_in, io.voff, y4 * io.row_bytes, 0);
+                const v4u rv = rcp[y4 / 4];
                 unsigned rcw[4] = {rv[0], rv[1], rv[2], rv[3]}, wq[4];
                 transpose4(rcw);
 #pragma unroll
@@ -256,20 +267,24 @@ __global__ __launch_bounds__(256) void mfma_trio_kernel(const TrioArgs a) {
             if (tid < 2 * TP) bufI[tid] = shI;
             st.store<false>(bufI, a.pad_in, tid);
         }
+        v4u rcp[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
+        rc_fetch(IC8(), Y, rcp);                                 // in flight during phase b
         if (nopad) inner(IC1(), IC0(), IC8(), bufA, bufB, Y + 1, std::false_type());
         else inner(IC1(), IC0(), IC8(), bufA, bufB, Y + 1, std::true_type());
         __syncthreads();
         shift(bufA);
-        outer(IC8(), Y);
+        outer(IC8(), Y, rcp);
         __syncthreads();
     }
     if (Y < y_end) {                                             // the closing half step: output rows Y .. Y+3
         shift(bufB);
         inner(IC0(), IC0(), IC4(), bufI, bufA, Y + 2, std::true_type());
         __syncthreads();
+        v4u rcp[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
+        rc_fetch(IC4(), Y, rcp);
         inner(IC1(), IC0(), IC4(), bufA, bufB, Y + 1, std::true_type());
         __syncthreads();
-        outer(IC4(), Y);
+        outer(IC4(), Y, rcp);
     }
 }
 

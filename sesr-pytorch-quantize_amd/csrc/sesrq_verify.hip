@@ -8,10 +8,12 @@
 //     q = x*r ;  rem = fma(-s, q, x) ;  q' = fma(rem, r, q)            (3 instructions)
 // which equals RN(x/s) for all but (possibly) pathological operands.  "Possibly" is not good
 // enough for a bit-exact path, so sesrq_create PROVES it for the net's own (s, z): a kernel
-// enumerates EVERY fp32 value x in [xlo, xhi] -- a range whose ends already saturate to -128 / 127,
-// inputs are clamped to it first -- and compares the final int8 of the fast form with the true
-// division.  ~2e9 values, about a millisecond of GPU time, cached per (s, z).  Any mismatch (or a
-// range that does not saturate) disables the fast path for that net.
+// enumerates EVERY fp32 value x in [xlo, xhi] -- the range whose ends quantise to exactly -128 and
+// 127, inputs are clamped to it first -- and compares the UNCLAMPED rint of the fast form with the
+// clamped true division: the chain is monotonic in x, so the clamp of x is the int8 clamp and the
+// kernels need no second one (round 3; before, the range ended 8 steps beyond and the result was
+// clamped again).  ~1e9 values, about a millisecond of GPU time, cached per (s, z).  Any mismatch
+// (or ends that do not land on -128 / 127) disables the fast path for that net.
 #include <cmath>
 #include <map>
 #include <mutex>
@@ -28,7 +30,7 @@ __device__ __forceinline__ float q8_fast(float x, float s, float r, float z) {
     const float q = __fmul_rn(x, r);
     const float rem = __builtin_fmaf(-s, q, x);
     const float q1 = __builtin_fmaf(rem, r, q);
-    return __builtin_amdgcn_fmed3f(rintf(__fadd_rn(q1, z)), -128.f, 127.f);
+    return rintf(__fadd_rn(q1, z));        // no clamp: x comes from [xlo, xhi] only
 }
 
 // bit patterns [b0, b1] (same sign, increasing magnitude)
@@ -46,18 +48,18 @@ static std::mutex g_mu;
 static std::map<std::pair<unsigned, int>, FastDiv> g_cache;
 
 // Option exact_div = 2: x * fl(1/s) on the proven form's instructions (r2 = 0).  x is clamped to the same saturating range
-// first -- multiplication by r > 0 is monotonic and both bounds quantise 8 steps beyond the int8 range, so the clamp changes no
-// result, and it keeps x * r finite (fma(-inf, 0, inf) would be NaN).  ok == 0 (division) if the range is degenerate.
+// first -- multiplication by r > 0 is monotonic and the bounds quantise to exactly -128 and 127 (checked), so clamping x IS the int8
+// clamp, and it keeps x * r finite (fma(-inf, 0, inf) would be NaN).  ok == 0 (division) if the range is degenerate.
 FastDiv reciprocal_form(float s, int zero) {
     FastDiv fd;
     fd.ok = 0; fd.r = 0.f; fd.r2 = 0.f; fd.xlo = 0.f; fd.xhi = 0.f;
     if (!(s > 0.f) || !std::isfinite(s)) return fd;
     fd.r = 1.0f / s;
-    fd.xlo = (float)((-136.0 - (double)zero) * (double)s);
-    fd.xhi = (float)((135.0 - (double)zero) * (double)s);
+    fd.xlo = (float)((-128.0 - (double)zero) * (double)s);
+    fd.xhi = (float)((127.0 - (double)zero) * (double)s);
     const float z = (float)zero;
-    const bool ok = std::isfinite(fd.r) && fd.r > 0.f && std::isfinite(fd.xlo) && std::isfinite(fd.xhi) &&
-                    rintf(fd.xlo * fd.r + z) <= -129.f && rintf(fd.xhi * fd.r + z) >= 128.f;
+    const bool ok = std::isfinite(fd.r) && fd.r > 0.f && std::isfinite(fd.xlo) && std::isfinite(fd.xhi) && fd.xlo < fd.xhi &&
+                    rintf(fd.xlo * fd.r + z) == -128.f && rintf(fd.xhi * fd.r + z) == 127.f;
     fd.ok = ok ? 1 : 0;
     return fd;
 }
@@ -74,9 +76,9 @@ FastDiv prove_fastdiv(float s, int zero) {
     }
     const float z = (float)zero;
     fd.r = fd.r2 = (float)(1.0L / (long double)s);
-    fd.xlo = (float)((-136.0 - (double)zero) * (double)s);
-    fd.xhi = (float)((135.0 - (double)zero) * (double)s);
-    bool ok = std::isfinite(fd.r) && std::isfinite(fd.xlo) && std::isfinite(fd.xhi) && fd.r > 0.f;
+    fd.xlo = (float)((-128.0 - (double)zero) * (double)s);
+    fd.xhi = (float)((127.0 - (double)zero) * (double)s);
+    bool ok = std::isfinite(fd.r) && std::isfinite(fd.xlo) && std::isfinite(fd.xhi) && fd.r > 0.f && fd.xlo < fd.xhi;
     unsigned long long *d_bad = nullptr;
     if (ok && hipMalloc((void **)&d_bad, sizeof(*d_bad)) == hipSuccess && hipMemset(d_bad, 0, sizeof(*d_bad)) == hipSuccess) {
         auto run = [&](float a, float b) {   // all floats between a and b, same sign, |a| <= |b|
@@ -87,9 +89,8 @@ FastDiv prove_fastdiv(float s, int zero) {
         else run(fd.xlo, fd.xhi);
         unsigned long long bad = 1;
         ok = hipMemcpy(&bad, d_bad, sizeof(bad), hipMemcpyDeviceToHost) == hipSuccess && bad == 0;
-        // the clamp range must saturate on both sides (host check with the exact formula)
-        const float lo_q = fminf(fmaxf(rintf(fd.xlo / s + z), -128.f), 127.f), hi_q = fminf(fmaxf(rintf(fd.xhi / s + z), -128.f), 127.f);
-        ok = ok && lo_q == -128.f && hi_q == 127.f;
+        // the ends of the clamp range must land on the ends of the int8 range (host check with the exact formula, unclamped)
+        ok = ok && rintf(fd.xlo / s + z) == -128.f && rintf(fd.xhi / s + z) == 127.f;
     } else {
         ok = false;
     }
