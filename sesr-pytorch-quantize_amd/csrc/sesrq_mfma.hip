@@ -644,6 +644,12 @@ __global__ __launch_bounds__(256) void mfma_h5p_kernel(const ConvArgs a) {
 // distinct even banks and the two lane groups of a 32-lane half an odd number of rows apart, i.e. on the odd banks.
 // NCH: input channels as a compile-time count (1 and 3 are the reference's nets), or 4 = "a.ic of them, tested per channel":
 // the wave-uniform test put every channel's load and quantise code into a block of its own.
+#ifndef SESRQ_F5_ZPAD
+#define SESRQ_F5_ZPAD 1       /* A/B knob: 0 = one descriptor over the image, row test + pad-word select per staged pixel */
+#endif
+#ifndef SESRQ_F5_VCONST
+#define SESRQ_F5_VCONST 1     /* A/B knob: 0 = the input quantiser's constants as scalar operands */
+#endif
 #ifndef SESRQ_F5_CARRY
 #define SESRQ_F5_CARRY 1      /* A/B knob: 0 = every tile of a run stages (loads + quantises) its whole window, halo rows included */
 #endif
@@ -652,17 +658,33 @@ struct StageFrame {
     __device__ __forceinline__ static bool has_channel(const ConvArgs &a, int c) { return NCH < 4 ? c < NCH : c < a.ic; }
     static constexpr int NIT = (SH * SWP + 255) / 256;
     static constexpr int ESZ = (SRC == SRC_F32) ? 4 : 1;
+    // ZPAD (fp32 frames): one buffer descriptor PER CHANNEL PLANE.  A pixel outside the frame -- column (lane offset 0x80000000), row
+    // above (negative total offset) or below (past the plane: the range check sees voffset + soffset, tools/oob_probe.hip) -- then
+    // loads 0.0f, and q0(0.0) = clamp8(z0) IS the pad value of the first layer (the zero point stands for 0.0): no row test, no
+    // select of a pad word.  With one descriptor over the whole image a row below plane c would read plane c + 1.
+    static constexpr bool ZPAD = SESRQ_F5_ZPAD && SRC == SRC_F32;
     unsigned raw[NIT][4];
     bool ok[NIT];
     int voff[NIT], ty[NIT];
-    __amdgpu_buffer_rsrc_t rs;
+    __amdgpu_buffer_rsrc_t rs, rsp[ZPAD ? (NCH < 4 ? NCH : 4) : 1];
     int row_bytes, plane_bytes;
+    InQuantV qc;
+    __device__ __forceinline__ static float pin(float x) { float r; asm volatile("s_nop 1\n\tv_mov_b32 %0, %1" : "=v"(r) : "s"(x)); return r; }
     __device__ __forceinline__ void init(const ConvArgs &a, int n_img, int x0, int tid) {
         const size_t HW = (size_t)a.H * a.W;
         const size_t img = HW * a.ic * ESZ;
         rs = __builtin_amdgcn_make_buffer_rsrc((char *)const_cast<void *>(a.in) + (size_t)n_img * img, 0, (int)img, 0x00020000);
         row_bytes = a.W * ESZ;
         plane_bytes = (int)(HW * ESZ);
+        if constexpr (ZPAD) {
+#pragma unroll
+            for (int c = 0; c < (NCH < 4 ? NCH : 4); ++c)
+                rsp[c] = __builtin_amdgcn_make_buffer_rsrc((char *)const_cast<void *>(a.in) + (size_t)n_img * img + (size_t)(c < a.ic ? c : 0) * plane_bytes, 0, plane_bytes, 0x00020000);
+        }
+        if constexpr (SRC != SRC_I8 && SESRQ_F5_VCONST) {
+            qc.xlo = pin(a.fd.xlo); qc.xhi = pin(a.fd.xhi); qc.r = pin(a.fd.r); qc.ns = pin(-a.s_in); qc.r2 = pin(a.fd.r2); qc.z = pin(a.z_in);
+            qc.magic = pin(MAGIC);
+        }
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
             const int i = tid + it * 256;
@@ -685,15 +707,21 @@ struct StageFrame {
         const int lo = 2 - y0 - R0, hi = a.H + 2 - y0 - R0;
 #pragma unroll
         for (int it = 0; it < N; ++it) {
-            ok[it] = (ty[it] >= lo) & (ty[it] < hi);
-            int vo = FIRST ? (ok[it] ? voff[it] + soff : (int)0x80000000) : voff[it];
+            int vo;
+            if constexpr (ZPAD) {
+                vo = FIRST ? voff[it] + soff : voff[it];      // no row test: the planes' own range checks return 0.0f = the pad value
+            } else {
+                ok[it] = (ty[it] >= lo) & (ty[it] < hi);
+                vo = FIRST ? (ok[it] ? voff[it] + soff : (int)0x80000000) : voff[it];
+            }
             if (!FIRST && CARRY && (it + 1) * 256 > (SH - CARRY) * SWP && threadIdx.x + it * 256 >= (SH - CARRY) * SWP) vo = (int)0x80000000;
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 raw[it][c] = 0;
                 if (has_channel(a, c)) {   // channel planes beyond ic are not loaded at all
                     const int so = (FIRST ? 0 : soff) + c * plane_bytes;
-                    if constexpr (SRC == SRC_F32) raw[it][c] = __builtin_amdgcn_raw_buffer_load_b32(rs, vo, so, 0);
+                    if constexpr (ZPAD) raw[it][c] = __builtin_amdgcn_raw_buffer_load_b32(rsp[c], vo, FIRST ? 0 : soff, 0);
+                    else if constexpr (SRC == SRC_F32) raw[it][c] = __builtin_amdgcn_raw_buffer_load_b32(rs, vo, so, 0);
                     else raw[it][c] = (unsigned)(int)(signed char)__builtin_amdgcn_raw_buffer_load_b8(rs, vo, so, 0);
                 }
             }
@@ -712,15 +740,17 @@ struct StageFrame {
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 if constexpr (SRC == SRC_F32)
-                    b[c] = quantize_in_bits(__builtin_bit_cast(float, raw[it][c]), a.s_in, a.z_in, a.fd);
+                    b[c] = SESRQ_F5_VCONST ? quantize_in_bits(__builtin_bit_cast(float, raw[it][c]), qc)
+                                           : quantize_in_bits(__builtin_bit_cast(float, raw[it][c]), a.s_in, a.z_in, a.fd);
                 else if constexpr (SRC == SRC_I8D)      // upstream net's int8 output: its float value, then this net's input quantiser
-                    b[c] = quantize_in_bits(__fmul_rn((float)(int)raw[it][c] - a.z_prev, a.s_prev), a.s_in, a.z_in, a.fd);
+                    b[c] = SESRQ_F5_VCONST ? quantize_in_bits(__fmul_rn((float)(int)raw[it][c] - a.z_prev, a.s_prev), qc)
+                                           : quantize_in_bits(__fmul_rn((float)(int)raw[it][c] - a.z_prev, a.s_prev), a.s_in, a.z_in, a.fd);
                 else
                     b[c] = raw[it][c];
                 if (!has_channel(a, c)) b[c] = 0;
             }
             int word = (int)pack_lo_bytes(b[0], b[1], b[2], b[3]);
-            if (!ok[it]) word = a.pad_word;
+            if constexpr (!ZPAD) { if (!ok[it]) word = a.pad_word; }
             if (i < (SH - R0) * SWP) cpw[(i % SWP) * PITCH + (i / SWP) + R0] = word;      // column-major: dword [column][row], column pitch PITCH
         }
         // The last iteration's registers are loaded by the first tile only and are free afterwards; waves that skip that iteration

@@ -69,6 +69,17 @@ __device__ __forceinline__ unsigned quantize_in_bits(float x, float s, float z, 
     return __builtin_bit_cast(unsigned, __fadd_rn(__fadd_rn(quotient_in(x, s, fd), z), 12582912.f));
 }
 
+// The same with every constant in a VGPR (InQuantV, filled once per kernel through in_vgpr()): a scalar-operand v_mul / v_fma /
+// v_add costs 2.1-2.3 ns per wave on gfx950, the all-VGPR form 1.4-1.5 (tools/op_cost_probe.hip) -- five such instructions per
+// value -- and v_med3 with two wave-uniform bounds needs one of them in a VGPR anyway (one SGPR per instruction).
+struct InQuantV { float xlo, xhi, r, ns, r2, z, magic; };
+__device__ __forceinline__ unsigned quantize_in_bits(float x, const InQuantV &c) {
+    const float xc = med3(x, c.xlo, c.xhi);
+    const float q = __fmul_rn(xc, c.r);
+    const float q1 = __builtin_fmaf(__builtin_fmaf(c.ns, q, xc), c.r2, q);
+    return __builtin_bit_cast(unsigned, __fadd_rn(__fadd_rn(q1, c.z), c.magic));
+}
+
 // A wave-uniform float pinned to a VGPR.  hipcc 7.2 (clang 22) un-packs a v_pk_fma_f32 that sits in the shadow of an MFMA into two
 // v_fma_f32; when the packed form read BOTH scalar operands out of one SGPR pair (s[n:n+1] with op_sel: 2^-n and the zero point
 // happen to be neighbours in the kernel arguments) the two halves become fma(v, s[n], s[n+1]) -- two scalar operands, illegal on
