@@ -374,6 +374,12 @@ int sesrq_create(const sesrq_net_desc *d, const sesrq_options *opts, sesrq_net *
         a.sh = ldexpf(1.0f, -(int)l.n);
         a.relu = l.relu;
         a.z_next = (float)d->zero[(k == 0 || k == L - 2) ? 1 : k + 1];
+        a.Md = a.Mf * a.sh; a.Cd = -(12582912.f * a.Mf) * a.sh;
+        {   // one-fma requant: the layer requantises into a -128 domain (z_next; the output layer: zero[L]) and (M, n) passes the proof
+            static const int knob = env_knob("SESRQ_DIRECT", 1, 0, 1);
+            const int zt = (k == L - 1) ? d->zero[L] : d->zero[(k == 0) ? 1 : k + 1];
+            a.direct = (knob && k != L - 2 && zt == -128 && prove_direct_requant(l.M, l.n)) ? 1 : 0;
+        }
         a.Mres = (float)d->M_res; a.shres = ldexpf(1.0f, -(int)d->n_res);
         a.z_merge = (float)d->zero[L - 1];
         a.s_in = d->scale_in; a.z_in = (float)d->zero[0];
@@ -472,6 +478,11 @@ const char *sesrq_layer_engine(const sesrq_net *net, int k) {
     return net->layers[k].engine.c_str();
 }
 
+int sesrq_layer_one_fma(const sesrq_net *net, int k) {
+    if (!net || k < 0 || k >= net->L) return 0;
+    return net->layers[k].base.direct;
+}
+
 int sesrq_launch_plan(const sesrq_net *net, int *first, int *count) {
     if (!net) return 0;
     int n = 0;
@@ -538,7 +549,7 @@ static int forward_impl(const sesrq_net *net, const void *in, int in_dtype, void
             for (int j = 0; j < 3; ++j) {
                 const LayerPlan &lj = net->layers[1 + j];
                 t.l[j].afrag = lj.d_afrag_merged;
-                t.l[j].Mf = lj.base.Mf; t.l[j].sh = lj.base.sh; t.l[j].z_next = lj.base.z_next;
+                t.l[j].Mf = lj.base.Mf; t.l[j].sh = lj.base.sh; t.l[j].z_next = lj.base.z_next; t.l[j].Md = lj.base.Md; t.l[j].Cd = lj.base.Cd; t.l[j].direct = lj.base.direct;
                 t.l[j].zlo = lj.base.relu ? fmaxf(lj.base.z_next, -128.f) : -128.f;
                 t.l[j].pad_next = net->layers[2 + j].base.pad_word;
             }
@@ -576,7 +587,7 @@ static int forward_impl(const sesrq_net *net, const void *in, int in_dtype, void
             for (int j = 0; j < 3; ++j) {
                 const LayerPlan &lj = net->layers[k + j];
                 t.l[j].afrag = lj.d_afrag_merged;
-                t.l[j].Mf = lj.base.Mf; t.l[j].sh = lj.base.sh; t.l[j].z_next = lj.base.z_next;
+                t.l[j].Mf = lj.base.Mf; t.l[j].sh = lj.base.sh; t.l[j].z_next = lj.base.z_next; t.l[j].Md = lj.base.Md; t.l[j].Cd = lj.base.Cd; t.l[j].direct = lj.base.direct;
                 t.l[j].zlo = lj.base.relu ? fmaxf(lj.base.z_next, -128.f) : -128.f;
                 t.l[j].pad_next = net->layers[k + j + 1].base.pad_word;
             }

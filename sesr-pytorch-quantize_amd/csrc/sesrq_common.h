@@ -114,6 +114,7 @@ struct FastDiv {
 };
 __host__ __device__ inline bool fd_reciprocal(const FastDiv &fd) { return fd.ok && fd.r2 == 0.f; }
 FastDiv prove_fastdiv(float s, int zero);
+bool prove_direct_requant(unsigned M, unsigned n);
 FastDiv reciprocal_form(float s, int zero);
 
 // Per-launch arguments of one conv layer.  Lives in the kernarg segment (SGPR loads).
@@ -142,6 +143,8 @@ struct ConvArgs {
     int pad_word;            // zc replicated into 4 bytes
     int acc_lo, acc_hi, add_lo, add_hi;
     float Mf, sh;            // (float)M, 2^-n
+    int direct;              // this layer's requant into a -128 domain as ONE fma (prove_direct_requant): Md, Cd below
+    float Md, Cd;            // M * 2^-n, -(1.5 * 2^23) * M * 2^-n
     float z_next;            // (float) zero of the domain this layer requantises into (+zero add)
     float Mres, shres;       // EPI_PRERES
     float z_merge;           // EPI_PRERES: zero of the last conv's input domain
@@ -159,6 +162,8 @@ struct TrioLayer {
     const int4 *afrag;       // merged A-fragment image of the layer (same as the per-layer MFMA kernel's)
     float Mf, sh, z_next;
     float zlo;               // lower clamp of the layer's output: relu ? max(z_next, -128) : -128
+    float Md, Cd;            // the one-fma requant (ConvArgs::direct); the trio kernel's U8 == 2 instance uses it for layers a and b
+    int direct;
     int pad_next;            // pad word (zc bytes) of the NEXT layer's input
 };
 struct TrioArgs {

@@ -92,8 +92,36 @@ struct LastStore {
     // shuffle-factor / row branches and no per-row offset selects in the hot loop of the SESR last layer
     // NV = 3: the lane's three real values are s[0..2] (s[3] is the padding row: never read).  FAST = 2 with NV = 3 is the
     // pair map of last_slot_oc (12 channels, PixelShuffle(2)): bytes 0, 1 = one 2-byte run, byte 2 = a single.
-    template <bool BIASED, int FAST = 0, int NV = 4>
+    // FASTD = FAST + 10: the same with the one-fma requant (ConvArgs::direct: zero point -128, (M, n) proven): cvt_pk_u8 does clamp,
+    // rounding and byte insertion -- per row 1 pk_fma + 1 fma + 3-4 cvt + 1 xor instead of 2 + 2 fma, 3-4 med3, 2 add, 1-3 perm
+    template <bool BIASED, int FASTD = 0, int NV = 4>
     __device__ __forceinline__ void store(const int s[4], const ConvArgs &a, int gy, float zlo, bool row_ok = true) const {
+        constexpr int FAST = FASTD % 10;
+        if constexpr (FASTD >= 10) {
+            static_assert(BIASED && FAST != 0, "one-fma requant: biased sums, int8 output");
+            const float cv = in_vgpr(a.Cd);
+            const v2f M2 = {a.Md, a.Md}, c2 = {cv, cv};
+            const v2f y01 = {__builtin_bit_cast(float, s[0]), __builtin_bit_cast(float, s[1])};
+            const v2f y23 = {__builtin_bit_cast(float, s[2]), __builtin_bit_cast(float, s[NV == 4 ? 3 : 2])};
+            const v2f w01 = __builtin_elementwise_fma(y01, M2, c2), w23 = __builtin_elementwise_fma(y23, M2, c2);
+            unsigned w = __builtin_amdgcn_cvt_pk_u8_f32(w01[0], 0, 0u);
+            w = __builtin_amdgcn_cvt_pk_u8_f32(w01[1], 1, w);
+            w = __builtin_amdgcn_cvt_pk_u8_f32(w23[0], 2, w);
+            if constexpr (NV == 4) w = __builtin_amdgcn_cvt_pk_u8_f32(w23[1], 3, w);
+            w ^= 0x80808080u;
+            const int so = __builtin_amdgcn_readfirstlane(row_ok ? gy * (FAST * FAST * a.W) : 0x7fff0000);
+            if constexpr (NV == 3) {
+                static_assert(FAST == 2, "three real rows per lane group: the PixelShuffle(2) pair map only");
+                __builtin_amdgcn_raw_buffer_store_b16((unsigned short)w, rq, this->vo[0], so, 0);
+                __builtin_amdgcn_raw_buffer_store_b8((unsigned char)(w >> 16), rq, this->vo[2], so, 0);
+            } else if constexpr (FAST == 2) {
+                __builtin_amdgcn_raw_buffer_store_b16((unsigned short)(w & 0xffffu), rq, this->vo[0], so, 0);
+                __builtin_amdgcn_raw_buffer_store_b16((unsigned short)(w >> 16), rq, this->vo[2], so, 0);
+            } else {
+                __builtin_amdgcn_raw_buffer_store_b32(w, rq, this->vo[0], so, 0);
+            }
+            return;
+        }
         v2f v01, v23;
         if constexpr (NV == 4) {
             requant4<BIASED>(s, a.Mf, a.sh, a.z_out, v01, v23);
@@ -894,7 +922,12 @@ __device__ __forceinline__ void mfma_f5_body(const ConvArgs &a, int4 *buf0, int4
                 }
             }
             // no separate residual tensor <=> zero[1] == -128 (sesrq_create) <=> this layer's z_next == -128: the cvt_pk_u8 epilogue
-            emit_rows4<EPI_MID, RC, BIASED, !RC && SESRQ_U8>(s4, a, io, y4, zlo);
+            if constexpr (!RC && SESRQ_U8 && BIASED) {      // wave-uniform: the one-fma requant where (M, n) passed its proof
+                if (a.direct) emit_rows4<EPI_MID, RC, BIASED, 2>(s4, a, io, y4, zlo);
+                else emit_rows4<EPI_MID, RC, BIASED, 1>(s4, a, io, y4, zlo);
+            } else {
+                emit_rows4<EPI_MID, RC, BIASED, (!RC && SESRQ_U8) ? 1 : 0>(s4, a, io, y4, zlo);
+            }
             b0 += 16; b1 += 16;
         }
     };
@@ -980,6 +1013,13 @@ static void launch_f5_sparse(const ConvArgs &a, hipStream_t st) {
         else if (mode == HYB) launch(KERN<HYB, __VA_ARGS__>, a, st);                     \
         else launch(KERN<GEN_ANY, __VA_ARGS__>, a, st);                                  \
     } while (0)
+// the one-fma last-layer flavours exist for the biased modes only (GEN_ANY sums carry no bias: it keeps the general store)
+#define SESRQ_BY_MODE_B(KERN, ...)                                                       \
+    do {                                                                                 \
+        if (mode == MERGED) launch(KERN<MERGED, __VA_ARGS__>, a, st);                    \
+        else if (mode == GEN_STD) launch(KERN<GEN_STD, __VA_ARGS__>, a, st);             \
+        else launch(KERN<HYB, __VA_ARGS__>, a, st);                                      \
+    } while (0)
 
 int launch_mfma(const LayerPlan &lp, const ConvArgs &a_in, int src, int epi, bool general, hipStream_t st, bool one_risky_pe, bool tap) {
     ConvArgs a = a_in;
@@ -1015,6 +1055,7 @@ int launch_mfma(const LayerPlan &lp, const ConvArgs &a_in, int src, int epi, boo
         if (e != hipSuccess) { set_error(std::string("mfma launch failed: ") + hipGetErrorString(e)); return 1; }
         return 0;
     }
+    const bool d1 = a.direct && mode != GEN_ANY && epi == EPI_LAST && a.z_out == -128.f && !a.anchor;
     switch (lp.mfma_kind) {
         case MFMA_H3:
             if (epi == EPI_MID) SESRQ_BY_MODE(mfma_h3_kernel, EPI_MID);
@@ -1030,12 +1071,14 @@ int launch_mfma(const LayerPlan &lp, const ConvArgs &a_in, int src, int epi, boo
             }
             if (epi == EPI_MID) SESRQ_BY_MODE(mfma_h5_kernel, EPI_MID);
             else if (epi == EPI_PRERES) SESRQ_BY_MODE(mfma_h5_kernel, EPI_PRERES);
+            // (below) d1: the output requant as one fma -- proven for this layer's (M, n), zero point -128, biased sums, int8 output only
+
             else if (last_nv(a.oc) == 3) {       // up to 12 output channels: three real rows per lane group (must match pack_mfma_frags)
-                if (a.out_q && !a.out_f && last_pairmap(a.oc, a.ps)) SESRQ_BY_MODE(mfma_h5_kernel, EPI_LAST, 2, 3);
+                if (a.out_q && !a.out_f && last_pairmap(a.oc, a.ps)) { if (d1) SESRQ_BY_MODE_B(mfma_h5_kernel, EPI_LAST, 12, 3); else SESRQ_BY_MODE(mfma_h5_kernel, EPI_LAST, 2, 3); }
                 else SESRQ_BY_MODE(mfma_h5_kernel, EPI_LAST, 0, 3);
             }
-            else if (a.out_q && !a.out_f && a.ps == 2) SESRQ_BY_MODE(mfma_h5_kernel, EPI_LAST, 2);
-            else if (a.out_q && !a.out_f && a.ps == 4) SESRQ_BY_MODE(mfma_h5_kernel, EPI_LAST, 4);
+            else if (a.out_q && !a.out_f && a.ps == 2) { if (d1) SESRQ_BY_MODE_B(mfma_h5_kernel, EPI_LAST, 12); else SESRQ_BY_MODE(mfma_h5_kernel, EPI_LAST, 2); }
+            else if (a.out_q && !a.out_f && a.ps == 4) { if (d1) SESRQ_BY_MODE_B(mfma_h5_kernel, EPI_LAST, 14); else SESRQ_BY_MODE(mfma_h5_kernel, EPI_LAST, 4); }
             else SESRQ_BY_MODE(mfma_h5_kernel, EPI_LAST);
             break;
         case MFMA_F5:

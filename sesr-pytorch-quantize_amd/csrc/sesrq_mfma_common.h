@@ -155,10 +155,26 @@ __device__ __forceinline__ unsigned round_pack_u8(v2f v01, v2f v23) {
 // U8: every zero point the epilogue adds is -128 (z_next; for the residual merge also z_merge): round_pack_u8
 
 // hidden layer: q = clamp8(rint(relu(t) + z_next))            (myQL/quan_func.py:280)
-template <bool BIASED, bool U8 = false, class AT>
+// U8 == 2: the one-fma requant (prove_direct_requant, sesrq_verify.hip): w = fl(s * M) * 2^-n straight into cvt_pk_u8 -- no second
+// fma, no "+ 128": per four values 2 pk_fma + 4 cvt + 1 xor instead of 4 pk_fma + 2 pk_add + 4 cvt + 1 xor
+template <bool BIASED, int U8 = 0, class AT>
 __device__ __forceinline__ unsigned epi_mid(const int s[4], const AT &a, float zlo) {
     v2f v01, v23;
-    if constexpr (U8) {
+    if constexpr (U8 == 2) {
+        static_assert(BIASED, "one-fma requant: biased sums only");
+        const float cv = in_vgpr(a.Cd);      // see in_vgpr(): Md and Cd are neighbours in the kernel arguments
+        const v2f M2 = {a.Md, a.Md}, c2 = {cv, cv};
+        const v2f y01 = {__builtin_bit_cast(float, s[0]), __builtin_bit_cast(float, s[1])};
+        const v2f y23 = {__builtin_bit_cast(float, s[2]), __builtin_bit_cast(float, s[3])};
+        v01 = __builtin_elementwise_fma(y01, M2, c2);
+        v23 = __builtin_elementwise_fma(y23, M2, c2);
+        unsigned w = __builtin_amdgcn_cvt_pk_u8_f32(v01[0], 0, 0u);
+        w = __builtin_amdgcn_cvt_pk_u8_f32(v01[1], 1, w);
+        w = __builtin_amdgcn_cvt_pk_u8_f32(v23[0], 2, w);
+        w = __builtin_amdgcn_cvt_pk_u8_f32(v23[1], 3, w);
+        return w ^ 0x80808080u;
+    }
+    if constexpr (U8 == 1) {
         requant4<BIASED>(s, a.Mf, a.sh, -128.f, v01, v23);
         return round_pack_u8(v01, v23);
     }
@@ -173,7 +189,7 @@ __device__ __forceinline__ unsigned epi_rc(const int s[4], const AT &a) {
     return round_pack(v01, v23, -128.f, 127.f);
 }
 // layer L-2: long residual merged in the integer domain        (myQL/quan_func.py:249-270)
-template <bool BIASED, bool U8 = false, class AT>
+template <bool BIASED, int U8 = 0, class AT>
 __device__ __forceinline__ unsigned epi_preres(const int s[4], unsigned rcword, const AT &a) {
     v2f v01, v23;
     requant4<BIASED>(s, a.Mf, a.sh, -128.f, v01, v23);
@@ -317,7 +333,7 @@ __device__ __forceinline__ void store_rows4(__amdgpu_buffer_rsrc_t rs, const Row
 }
 
 // hidden-layer output of 4 rows: s4[r][i] -> requant -> transpose -> one 16-byte store per lane
-template <int EPI, bool RC, bool BIASED, bool U8 = false, class AT>
+template <int EPI, bool RC, bool BIASED, int U8 = 0, class AT>
 __device__ __forceinline__ void emit_rows4(const int s4[4][4], const AT &a, const RowIO &io, int y4, float zlo) {
     unsigned w[4];
     if constexpr (EPI == EPI_PRERES) {
@@ -331,7 +347,7 @@ __device__ __forceinline__ void emit_rows4(const int s4[4][4], const AT &a, cons
             transpose4(rcw);
         }
 #pragma unroll
-        for (int r = 0; r < 4; ++r) w[r] = epi_preres<BIASED, U8>(s4[r], rcw[r], a);
+        for (int r = 0; r < 4; ++r) w[r] = epi_preres<BIASED, (U8 != 0)>(s4[r], rcw[r], a);
     } else {
 #pragma unroll
         for (int r = 0; r < 4; ++r) w[r] = epi_mid<BIASED, U8>(s4[r], a, zlo);

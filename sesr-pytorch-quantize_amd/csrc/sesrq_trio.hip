@@ -95,11 +95,12 @@ struct TrioStage {
 };
 
 struct TrioEpiC {           // the field names the shared epilogues read
-    float Mf, sh, z_next, Mres, shres, z_merge;
+    float Mf, sh, z_next, Mres, shres, z_merge, Md, Cd;
 };
 
-// U8: every zero point of the three epilogues is -128 (the launch checks): round_pack_u8 (sesrq_mfma_common.h)
-template <int EPI_C, bool U8>
+// U8 = 1: every zero point of the three epilogues is -128 (the launch checks): round_pack_u8 (sesrq_mfma_common.h)
+// U8 = 2: and the plain (non-merging) layers' requants passed prove_direct_requant: the one-fma form of epi_mid
+template <int EPI_C, int U8>
 __global__ __launch_bounds__(256) void mfma_trio_kernel(const TrioArgs a) {
     extern __shared__ int4 trio_lds[];             // dynamic: the launch pads the size so that exactly `occ` workgroups fit a CU
     int4 *bufI = trio_lds, *bufA = trio_lds + TRIO_WIN, *bufB = trio_lds + 2 * TRIO_WIN;
@@ -144,7 +145,7 @@ __global__ __launch_bounds__(256) void mfma_trio_kernel(const TrioArgs a) {
     io.rc_out = io.out;
     io.row_bytes = a.W * 16;
     const int voff_c = col_out ? (g * a.W + gx) * 16 : OOB;       // + Y * row_bytes per step
-    const TrioEpiC ec = {a.l[2].Mf, a.l[2].sh, a.l[2].z_next, a.Mres, a.shres, a.z_merge};
+    const TrioEpiC ec = {a.l[2].Mf, a.l[2].sh, a.l[2].z_next, a.Mres, a.shres, a.z_merge, a.l[2].Md, a.l[2].Cd};
 
     // inner layer K: window position 2+i <- positions i .. i+2 of the source window; row0 = frame row of i = 0.
     // Written row by row: hipcc keeps ONE accumulator and serialises chain -> epilogue per row, the other three waves of the
@@ -316,9 +317,17 @@ int launch_trio(const TrioArgs &a, int epi_c, hipStream_t st) {
     if (epi_c == EPI_PRERES) u8 = u8 && a.z_merge == -128.f;
     else u8 = u8 && a.l[2].z_next == -128.f && a.l[2].zlo == -128.f;
     if (!SESRQ_U8) u8 = false;                     // A/B build knob
-    if (epi_c == EPI_PRERES) { if (u8) launch_trio_k(mfma_trio_kernel<EPI_PRERES, true>, a, st); else launch_trio_k(mfma_trio_kernel<EPI_PRERES, false>, a, st); }
-    else if (epi_c == EPI_MID) { if (u8) launch_trio_k(mfma_trio_kernel<EPI_MID, true>, a, st); else launch_trio_k(mfma_trio_kernel<EPI_MID, false>, a, st); }
-    else { set_error("trio: the third layer must be a hidden layer"); return 1; }
+    const bool direct = u8 && a.l[0].direct && a.l[1].direct && (epi_c == EPI_PRERES || a.l[2].direct);      // one-fma requants (proof per layer)
+    const int mode = direct ? 2 : (u8 ? 1 : 0);
+    if (epi_c == EPI_PRERES) {
+        if (mode == 2) launch_trio_k(mfma_trio_kernel<EPI_PRERES, 2>, a, st);
+        else if (mode == 1) launch_trio_k(mfma_trio_kernel<EPI_PRERES, 1>, a, st);
+        else launch_trio_k(mfma_trio_kernel<EPI_PRERES, 0>, a, st);
+    } else if (epi_c == EPI_MID) {
+        if (mode == 2) launch_trio_k(mfma_trio_kernel<EPI_MID, 2>, a, st);
+        else if (mode == 1) launch_trio_k(mfma_trio_kernel<EPI_MID, 1>, a, st);
+        else launch_trio_k(mfma_trio_kernel<EPI_MID, 0>, a, st);
+    } else { set_error("trio: the third layer must be a hidden layer"); return 1; }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { set_error(std::string("trio launch failed: ") + hipGetErrorString(e)); return 1; }
     return 0;

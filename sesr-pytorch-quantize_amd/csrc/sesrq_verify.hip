@@ -101,4 +101,32 @@ FastDiv prove_fastdiv(float s, int zero) {
     return fd;
 }
 
+// One-fma requant into a domain whose zero point is -128 (hidden layers behind ReLU, the output layer: every reference bundle).
+// The reference value is q = clamp8(rint(fl(t' - 128))) with t' = fl(s * M) * 2^-n (myQL/quan_func.py:280; relu's clamp is the int8
+// clamp here); the kernels' cvt_pk_u8 form evaluates cvt_u8(fl(fl(t' - 128) + 128)) - 128, proven equal for EVERY fp32 t'
+// (tools/cvtpk_epilogue_probe.hip).  fl(t' - 128) is exact for t' >= 64 (Sterbenz) and rounds t' to the 2^-17 grid below, so
+// cvt_u8(t') itself -- t' straight out of ONE fma, fl((MAGIC + s) * (M 2^-n) - MAGIC * M 2^-n) = fl(s * M) * 2^-n, no "- 128",
+// no "+ 128" -- differs only where some reachable t' < 64 lies within 2^-18 of a half-integer without being one.  Whether that
+// happens depends on (M, n) alone: all s whose t' lies in [-2, 258] are enumerated (a few 1e5 values; outside both forms
+// saturate), with the device's operations restated in host fp32 (this file is built with -ffp-contract=off).
+bool prove_direct_requant(unsigned M, unsigned n) {
+    if (M == 0 || 3ull * M >= (1ull << 18) || n > 40) return false;          // MAGIC * M must be exact (the biased form's own condition)
+    const float Mf = (float)M, sh = ldexpf(1.0f, -(int)n), Md = Mf * sh, Cd = -(12582912.f * Mf) * sh;
+    const double scale = (double)M * ldexp(1.0, -(int)n);
+    long long s_lo = (long long)floor(-2.0 / scale), s_hi = (long long)ceil(258.0 / scale);
+    const long long lim = (1ll << 22) - 1;
+    if (s_lo < -lim) s_lo = -lim;
+    if (s_hi > lim) s_hi = lim;
+    auto cvt_u8 = [](float w) { const float r = rintf(w); return r < 0.f ? 0.f : (r > 255.f ? 255.f : r); };
+    for (long long s = s_lo; s <= s_hi; ++s) {
+        const float y = 12582912.f + (float)s;                                 // bits = MAGIC_I + s: exact for |s| < 2^22
+        const float t = fmaf(y, Mf, -(12582912.f * Mf));                       // fl(s * M)
+        const float v = fmaf(t, sh, -128.f);                                   // the kernels' second fma
+        const float ref = cvt_u8(v + 128.f);
+        const float one = cvt_u8(fmaf(y, Md, Cd));
+        if (ref != one) return false;
+    }
+    return true;
+}
+
 }  // namespace sesrq

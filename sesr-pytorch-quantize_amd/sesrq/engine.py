@@ -126,6 +126,10 @@ class Engine:
     def fast_division_proven(self) -> bool:
         return bool(_lib.lib().sesrq_fast_division_proven(self._h))
 
+    def one_fma_layers(self):
+        """Per layer: does its requant run as ONE fused multiply-add (sesrq_layer_one_fma: proven per (M, n) at create)?"""
+        return [bool(_lib.lib().sesrq_layer_one_fma(self._h, k)) for k in range(self.bundle.L)]
+
     def layer_engines(self):
         return [(_lib.lib().sesrq_layer_engine(self._h, k) or b"").decode() for k in range(self.bundle.L)]
 
