@@ -378,7 +378,8 @@ int sesrq_create(const sesrq_net_desc *d, const sesrq_options *opts, sesrq_net *
         {   // one-fma requant: the layer requantises into a -128 domain (z_next; the output layer: zero[L]) and (M, n) passes the proof
             static const int knob = env_knob("SESRQ_DIRECT", 1, 0, 1);
             const int zt = (k == L - 1) ? d->zero[L] : d->zero[(k == 0) ? 1 : k + 1];
-            a.direct = (knob && k != L - 2 && zt == -128 && prove_direct_requant(l.M, l.n)) ? 1 : 0;
+            // the residual-merging layer L-2: its FIRST requant, into the fixed -128 domain of ic (quan_func.py:250), whatever the zero points
+            a.direct = (knob && (k == L - 2 || zt == -128) && prove_direct_requant(l.M, l.n)) ? 1 : 0;
         }
         a.Mres = (float)d->M_res; a.shres = ldexpf(1.0f, -(int)d->n_res);
         a.z_merge = (float)d->zero[L - 1];

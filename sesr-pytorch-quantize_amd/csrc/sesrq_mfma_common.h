@@ -216,14 +216,31 @@ __device__ __forceinline__ unsigned epi_preres(const int s[4], unsigned rcword, 
 // address lut_addr < 2^15).  The rounding constant also carries the table's address: c = ic + (MAGIC + 256 + lut_addr) is exact
 // (ulp 1), its low 16 bits are lut_addr + (ic + 256), and adding the signed rc byte to them (one v_add_u32_sdwa) IS the LDS address
 // of q4(u): per value 2 fma + med3 + add + sdwa-add + one byte read (+ 1/4 v_lshl_or), no second requant, no byte shuffles.
-template <bool BIASED, class AT>
+// ONE_FMA (prove_direct_requant for this layer's (M, n)): w = fl(s * M) * 2^-n out of one fma, ic + 128 = rint(clamp(w, 0, 255)) --
+// the "- 128" moves from the requant into the rounding constant (lut_magic - 128): one pk_fma per two values less.
+template <bool BIASED, bool ONE_FMA = false, class AT>
 __device__ __forceinline__ unsigned epi_preres_lut(const int s[4], unsigned rcword, const AT &a, float lut_magic) {
     typedef const unsigned char __attribute__((address_space(3))) *lds_u8_t;
     v2f v01, v23;
-    requant4<BIASED>(s, a.Mf, a.sh, -128.f, v01, v23);
-    const v2f mg = {lut_magic, lut_magic};                     // MAGIC + 256 + lut_addr: the low 16 bits of c are lut_addr + (ic + 256)
-    v2f c01 = {med3(v01[0], -128.f, 127.f), med3(v01[1], -128.f, 127.f)}, c23 = {med3(v23[0], -128.f, 127.f), med3(v23[1], -128.f, 127.f)};
-    c01 = c01 + mg; c23 = c23 + mg;
+    v2f c01, c23;
+    if constexpr (ONE_FMA) {
+        static_assert(BIASED, "one-fma requant: biased sums only");
+        const float cv = in_vgpr(a.Cd);
+        const v2f M2 = {a.Md, a.Md}, c2 = {cv, cv};
+        const v2f y01 = {__builtin_bit_cast(float, s[0]), __builtin_bit_cast(float, s[1])};
+        const v2f y23 = {__builtin_bit_cast(float, s[2]), __builtin_bit_cast(float, s[3])};
+        v01 = __builtin_elementwise_fma(y01, M2, c2);
+        v23 = __builtin_elementwise_fma(y23, M2, c2);
+        const float m128 = lut_magic - 128.f;                  // MAGIC + 128 + lut_addr (exact): low 16 bits of c = lut_addr + (ic + 128) + 128
+        const v2f mg = {m128, m128};
+        c01 = (v2f){med3(v01[0], 0.f, 255.f), med3(v01[1], 0.f, 255.f)}; c23 = (v2f){med3(v23[0], 0.f, 255.f), med3(v23[1], 0.f, 255.f)};
+        c01 = c01 + mg; c23 = c23 + mg;
+    } else {
+        requant4<BIASED>(s, a.Mf, a.sh, -128.f, v01, v23);
+        const v2f mg = {lut_magic, lut_magic};                 // MAGIC + 256 + lut_addr: the low 16 bits of c are lut_addr + (ic + 256)
+        c01 = (v2f){med3(v01[0], -128.f, 127.f), med3(v01[1], -128.f, 127.f)}; c23 = (v2f){med3(v23[0], -128.f, 127.f), med3(v23[1], -128.f, 127.f)};
+        c01 = c01 + mg; c23 = c23 + mg;
+    }
     // + the SIGNED rc byte (v_add_u32_sdwa, WORD_0 + sign-extended BYTE_k): lut_addr + (rc + ic + 256) = the address of q4(u)
     const unsigned a0 = (fbits(c01[0]) & 0xffffu) + (unsigned)(int)(signed char)(rcword), a1 = (fbits(c01[1]) & 0xffffu) + (unsigned)(int)(signed char)(rcword >> 8);
     const unsigned a2 = (fbits(c23[0]) & 0xffffu) + (unsigned)(int)(signed char)(rcword >> 16), a3 = (fbits(c23[1]) & 0xffffu) + (unsigned)((int)rcword >> 24);

@@ -98,8 +98,9 @@ struct TrioEpiC {           // the field names the shared epilogues read
     float Mf, sh, z_next, Mres, shres, z_merge, Md, Cd;
 };
 
-// U8 = 1: every zero point of the three epilogues is -128 (the launch checks): round_pack_u8 (sesrq_mfma_common.h)
-// U8 = 2: and the plain (non-merging) layers' requants passed prove_direct_requant: the one-fma form of epi_mid
+// U8, a bit mask: 1 = every zero point of the three epilogues is -128 (the launch checks): round_pack_u8 (sesrq_mfma_common.h);
+// 2 = the requants of layers a and b passed prove_direct_requant: the one-fma form of epi_mid; 4 = so did the third layer's
+// (residual merge: its first requant, into the fixed -128 domain of ic).  Instances: 0, 1, 3, 7
 template <int EPI_C, int U8>
 __global__ __launch_bounds__(256) void mfma_trio_kernel(const TrioArgs a) {
     extern __shared__ int4 trio_lds[];             // dynamic: the launch pads the size so that exactly `occ` workgroups fit a CU
@@ -171,7 +172,7 @@ __global__ __launch_bounds__(256) void mfma_trio_kernel(const TrioArgs a) {
             acc = mfma(A[K][2], B2, acc);
             B0 = B1; B1 = B2;
             const int s[4] = {acc[0], acc[1], acc[2], acc[3]};
-            unsigned q = epi_mid<true, U8>(s, L, L.zlo);
+            unsigned q = epi_mid<true, (U8 & 2) ? 2 : (U8 & 1)>(s, L, L.zlo);
             if constexpr (PAD) {
                 const int row = row0 + i;
                 const bool rok = (row >= 0) & (row < a.H);
@@ -216,10 +217,10 @@ __global__ __launch_bounds__(256) void mfma_trio_kernel(const TrioArgs a) {
                 unsigned rcw[4] = {rv[0], rv[1], rv[2], rv[3]}, wq[4];
                 transpose4(rcw);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) wq[r] = epi_preres_lut<true>(s4[r], rcw[r], ec, lut_magic);
+                for (int r = 0; r < 4; ++r) wq[r] = epi_preres_lut<true, (U8 & 4) != 0>(s4[r], rcw[r], ec, lut_magic);
                 store_rows4(io.out, io, y4, wq);
             } else {
-                emit_rows4<EPI_C, false, true, U8>(s4, ec, io, y4, a.l[2].zlo);
+                emit_rows4<EPI_C, false, true, (U8 & 4) ? 2 : (U8 & 1)>(s4, ec, io, y4, a.l[2].zlo);
             }
         }
     };
@@ -317,14 +318,16 @@ int launch_trio(const TrioArgs &a, int epi_c, hipStream_t st) {
     if (epi_c == EPI_PRERES) u8 = u8 && a.z_merge == -128.f;
     else u8 = u8 && a.l[2].z_next == -128.f && a.l[2].zlo == -128.f;
     if (!SESRQ_U8) u8 = false;                     // A/B build knob
-    const bool direct = u8 && a.l[0].direct && a.l[1].direct && (epi_c == EPI_PRERES || a.l[2].direct);      // one-fma requants (proof per layer)
-    const int mode = direct ? 2 : (u8 ? 1 : 0);
+    const bool ab = u8 && a.l[0].direct && a.l[1].direct, abc = ab && a.l[2].direct;      // one-fma requants (proof per layer)
+    const int mode = abc ? 7 : (ab ? 3 : (u8 ? 1 : 0));
     if (epi_c == EPI_PRERES) {
-        if (mode == 2) launch_trio_k(mfma_trio_kernel<EPI_PRERES, 2>, a, st);
+        if (mode == 7) launch_trio_k(mfma_trio_kernel<EPI_PRERES, 7>, a, st);
+        else if (mode == 3) launch_trio_k(mfma_trio_kernel<EPI_PRERES, 3>, a, st);
         else if (mode == 1) launch_trio_k(mfma_trio_kernel<EPI_PRERES, 1>, a, st);
         else launch_trio_k(mfma_trio_kernel<EPI_PRERES, 0>, a, st);
     } else if (epi_c == EPI_MID) {
-        if (mode == 2) launch_trio_k(mfma_trio_kernel<EPI_MID, 2>, a, st);
+        if (mode == 7) launch_trio_k(mfma_trio_kernel<EPI_MID, 7>, a, st);
+        else if (mode == 3) launch_trio_k(mfma_trio_kernel<EPI_MID, 3>, a, st);
         else if (mode == 1) launch_trio_k(mfma_trio_kernel<EPI_MID, 1>, a, st);
         else launch_trio_k(mfma_trio_kernel<EPI_MID, 0>, a, st);
     } else { set_error("trio: the third layer must be a hidden layer"); return 1; }

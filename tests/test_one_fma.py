@@ -73,7 +73,8 @@ def expected_flags(net: O.Net):
     out = []
     for k, l in enumerate(net.layers):
         zt = net.zero[L] if k == L - 1 else net.zero[1 if k == 0 else k + 1]
-        out.append(bool(k != L - 2 and zt == -128 and one_fma_verdict(l.M, l.n)[0]))
+        # the residual-merging layer L-2: its first requant goes into the fixed -128 domain of ic, whatever the zero points
+        out.append(bool((k == L - 2 or zt == -128) and one_fma_verdict(l.M, l.n)[0]))
     return out
 
 
