@@ -113,11 +113,12 @@ void sesrq_destroy(sesrq_net *net);
 /* 1 if sesrq_create proved (exhaustively, on the device) that the 3-instruction reciprocal form of
  * the input quantiser's x / scale_in is bit-identical for this net; 0 = IEEE division is used. */
 int sesrq_fast_division_proven(const sesrq_net *net);
-/* 1 if sesrq_create proved (all reachable sums enumerated on the host) that layer k's requant into its -128 domain,
+/* 1 (2: see below) if sesrq_create proved (all reachable sums enumerated on the host) that layer k's requant into its -128 domain,
  * clamp8(rint(fl(fl(s * M) * 2^-n - 128))) (myQL/quan_func.py:280; the output layer: :601), is bit-identical to ONE fused
  * multiply-add followed by the saturating byte convert, and the MFMA kernels therefore run that form; 0 = the two-step form
  * (other zero points, a (M, n) that fails the proof, SESRQ_DIRECT=0).  For the residual-merging layer L-2 the flag speaks of its
- * first requant (into the fixed -128 domain of ic, quan_func.py:250).  No reference counterpart. */
+ * first requant (into the fixed -128 domain of ic, quan_func.py:250).  2 (output layer only): the one-fma form failed, but one fma
+ * that also subtracts the 128 (a single rounding of s * M * 2^-n - 128) followed by the add of 128 is proven identical: that form runs.  No reference counterpart. */
 int sesrq_layer_one_fma(const sesrq_net *net, int k);
 
 /* Bytes of device workspace sesrq_forward needs for N frames of H x W (caller-owned). */

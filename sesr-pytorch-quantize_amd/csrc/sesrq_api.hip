@@ -380,6 +380,9 @@ int sesrq_create(const sesrq_net_desc *d, const sesrq_options *opts, sesrq_net *
             const int zt = (k == L - 1) ? d->zero[L] : d->zero[(k == 0) ? 1 : k + 1];
             // the residual-merging layer L-2: its FIRST requant, into the fixed -128 domain of ic (quan_func.py:250), whatever the zero points
             a.direct = (knob && (k == L - 2 || zt == -128) && prove_direct_requant(l.M, l.n)) ? 1 : 0;
+            // the output layer's second choice (LastStore, FASTD 2x): one fma that also subtracts the 128, and the add back
+            if (knob && !a.direct && k == L - 1 && zt == -128 && prove_single_requant(l.M, l.n)) a.direct = 2;
+            a.Cs = a.Cd - 128.f;
         }
         a.Mres = (float)d->M_res; a.shres = ldexpf(1.0f, -(int)d->n_res);
         a.z_merge = (float)d->zero[L - 1];
@@ -481,7 +484,7 @@ const char *sesrq_layer_engine(const sesrq_net *net, int k) {
 
 int sesrq_layer_one_fma(const sesrq_net *net, int k) {
     if (!net || k < 0 || k >= net->L) return 0;
-    return net->layers[k].base.direct;
+    return net->layers[k].base.direct;      // 1 = one fma, 2 = one fma + the add of 128 (output layer only)
 }
 
 int sesrq_launch_plan(const sesrq_net *net, int *first, int *count) {

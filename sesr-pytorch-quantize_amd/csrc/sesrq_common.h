@@ -115,6 +115,7 @@ struct FastDiv {
 __host__ __device__ inline bool fd_reciprocal(const FastDiv &fd) { return fd.ok && fd.r2 == 0.f; }
 FastDiv prove_fastdiv(float s, int zero);
 bool prove_direct_requant(unsigned M, unsigned n);
+bool prove_single_requant(unsigned M, unsigned n);
 FastDiv reciprocal_form(float s, int zero);
 
 // Per-launch arguments of one conv layer.  Lives in the kernarg segment (SGPR loads).
@@ -143,8 +144,9 @@ struct ConvArgs {
     int pad_word;            // zc replicated into 4 bytes
     int acc_lo, acc_hi, add_lo, add_hi;
     float Mf, sh;            // (float)M, 2^-n
-    int direct;              // this layer's requant into a -128 domain as ONE fma (prove_direct_requant): Md, Cd below
-    float Md, Cd;            // M * 2^-n, -(1.5 * 2^23) * M * 2^-n
+    int direct;              // this layer's requant into a -128 domain: 1 = as ONE fma (prove_direct_requant: Md, Cd), 2 = as one fma that
+                             // also subtracts the 128, plus the add that brings it back (prove_single_requant: Md, Cs), 0 = the two-step form
+    float Md, Cd, Cs;        // M * 2^-n, -(1.5 * 2^23) * M * 2^-n, Cd - 128
     float z_next;            // (float) zero of the domain this layer requantises into (+zero add)
     float Mres, shres;       // EPI_PRERES
     float z_merge;           // EPI_PRERES: zero of the last conv's input domain

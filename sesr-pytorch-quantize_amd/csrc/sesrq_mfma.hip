@@ -99,11 +99,13 @@ struct LastStore {
         constexpr int FAST = FASTD % 10;
         if constexpr (FASTD >= 10) {
             static_assert(BIASED && FAST != 0, "one-fma requant: biased sums, int8 output");
-            const float cv = in_vgpr(a.Cd);
+            // FASTD 2x (ConvArgs::direct == 2): the fma also subtracts the 128 (one rounding of s*M*2^-n - 128), one add brings it back
+            const float cv = in_vgpr(FASTD >= 20 ? a.Cs : a.Cd);
             const v2f M2 = {a.Md, a.Md}, c2 = {cv, cv};
             const v2f y01 = {__builtin_bit_cast(float, s[0]), __builtin_bit_cast(float, s[1])};
             const v2f y23 = {__builtin_bit_cast(float, s[2]), __builtin_bit_cast(float, s[NV == 4 ? 3 : 2])};
-            const v2f w01 = __builtin_elementwise_fma(y01, M2, c2), w23 = __builtin_elementwise_fma(y23, M2, c2);
+            v2f w01 = __builtin_elementwise_fma(y01, M2, c2), w23 = __builtin_elementwise_fma(y23, M2, c2);
+            if constexpr (FASTD >= 20) { const v2f k = {128.f, 128.f}; w01 = w01 + k; w23 = w23 + k; }
             unsigned w = __builtin_amdgcn_cvt_pk_u8_f32(w01[0], 0, 0u);
             w = __builtin_amdgcn_cvt_pk_u8_f32(w01[1], 1, w);
             w = __builtin_amdgcn_cvt_pk_u8_f32(w23[0], 2, w);
@@ -1055,7 +1057,8 @@ int launch_mfma(const LayerPlan &lp, const ConvArgs &a_in, int src, int epi, boo
         if (e != hipSuccess) { set_error(std::string("mfma launch failed: ") + hipGetErrorString(e)); return 1; }
         return 0;
     }
-    const bool d1 = a.direct && mode != GEN_ANY && epi == EPI_LAST && a.z_out == -128.f && !a.anchor;
+    const bool dl = a.direct && mode != GEN_ANY && epi == EPI_LAST && a.z_out == -128.f && !a.anchor;
+    const bool d1 = dl && a.direct == 1, d2 = dl && a.direct == 2;
     switch (lp.mfma_kind) {
         case MFMA_H3:
             if (epi == EPI_MID) SESRQ_BY_MODE(mfma_h3_kernel, EPI_MID);
@@ -1074,11 +1077,11 @@ int launch_mfma(const LayerPlan &lp, const ConvArgs &a_in, int src, int epi, boo
             // (below) d1: the output requant as one fma -- proven for this layer's (M, n), zero point -128, biased sums, int8 output only
 
             else if (last_nv(a.oc) == 3) {       // up to 12 output channels: three real rows per lane group (must match pack_mfma_frags)
-                if (a.out_q && !a.out_f && last_pairmap(a.oc, a.ps)) { if (d1) SESRQ_BY_MODE_B(mfma_h5_kernel, EPI_LAST, 12, 3); else SESRQ_BY_MODE(mfma_h5_kernel, EPI_LAST, 2, 3); }
+                if (a.out_q && !a.out_f && last_pairmap(a.oc, a.ps)) { if (d1) SESRQ_BY_MODE_B(mfma_h5_kernel, EPI_LAST, 12, 3); else if (d2) SESRQ_BY_MODE_B(mfma_h5_kernel, EPI_LAST, 22, 3); else SESRQ_BY_MODE(mfma_h5_kernel, EPI_LAST, 2, 3); }
                 else SESRQ_BY_MODE(mfma_h5_kernel, EPI_LAST, 0, 3);
             }
-            else if (a.out_q && !a.out_f && a.ps == 2) { if (d1) SESRQ_BY_MODE_B(mfma_h5_kernel, EPI_LAST, 12); else SESRQ_BY_MODE(mfma_h5_kernel, EPI_LAST, 2); }
-            else if (a.out_q && !a.out_f && a.ps == 4) { if (d1) SESRQ_BY_MODE_B(mfma_h5_kernel, EPI_LAST, 14); else SESRQ_BY_MODE(mfma_h5_kernel, EPI_LAST, 4); }
+            else if (a.out_q && !a.out_f && a.ps == 2) { if (d1) SESRQ_BY_MODE_B(mfma_h5_kernel, EPI_LAST, 12); else if (d2) SESRQ_BY_MODE_B(mfma_h5_kernel, EPI_LAST, 22); else SESRQ_BY_MODE(mfma_h5_kernel, EPI_LAST, 2); }
+            else if (a.out_q && !a.out_f && a.ps == 4) { if (d1) SESRQ_BY_MODE_B(mfma_h5_kernel, EPI_LAST, 14); else if (d2) SESRQ_BY_MODE_B(mfma_h5_kernel, EPI_LAST, 24); else SESRQ_BY_MODE(mfma_h5_kernel, EPI_LAST, 4); }
             else SESRQ_BY_MODE(mfma_h5_kernel, EPI_LAST);
             break;
         case MFMA_F5:

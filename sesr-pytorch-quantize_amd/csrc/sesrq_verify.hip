@@ -129,4 +129,28 @@ bool prove_direct_requant(unsigned M, unsigned n) {
     return true;
 }
 
+// Second candidate where the first fails: v = fl(s * M * 2^-n - 128) out of ONE fma (a single rounding of the exact value; the
+// reference rounds s * M first), then cvt_u8(fl(v + 128)) as in the two-step form: one fma less than that.  The two roundings
+// differ for other s than the one-fma form's (e.g. (M, n) = (32865, 24): one-fma fails for one s of 132 729, this form for none;
+// (44669, 25): the other way round), so a layer takes whichever its (M, n) allows.  Same enumeration.
+bool prove_single_requant(unsigned M, unsigned n) {
+    if (M == 0 || 3ull * M >= (1ull << 18) || n > 38) return false;
+    const float Mf = (float)M, sh = ldexpf(1.0f, -(int)n), Md = Mf * sh, Cd = -(12582912.f * Mf) * sh, Cs = Cd - 128.f;
+    if ((double)Cs != (double)Cd - 128.0) return false;                        // the fma's addend must be exact
+    const double scale = (double)M * ldexp(1.0, -(int)n);
+    long long s_lo = (long long)floor(-2.0 / scale), s_hi = (long long)ceil(258.0 / scale);
+    const long long lim = (1ll << 22) - 1;
+    if (s_lo < -lim) s_lo = -lim;
+    if (s_hi > lim) s_hi = lim;
+    auto cvt_u8 = [](float w) { const float r = rintf(w); return r < 0.f ? 0.f : (r > 255.f ? 255.f : r); };
+    for (long long s = s_lo; s <= s_hi; ++s) {
+        const float y = 12582912.f + (float)s;
+        const float t = fmaf(y, Mf, -(12582912.f * Mf));
+        const float ref = cvt_u8(fmaf(t, sh, -128.f) + 128.f);
+        const float one = cvt_u8(fmaf(y, Md, Cs) + 128.f);
+        if (ref != one) return false;
+    }
+    return true;
+}
+
 }  // namespace sesrq

@@ -127,8 +127,9 @@ class Engine:
         return bool(_lib.lib().sesrq_fast_division_proven(self._h))
 
     def one_fma_layers(self):
-        """Per layer: does its requant run as ONE fused multiply-add (sesrq_layer_one_fma: proven per (M, n) at create)?"""
-        return [bool(_lib.lib().sesrq_layer_one_fma(self._h, k)) for k in range(self.bundle.L)]
+        """Per layer, the form of its requant (sesrq_layer_one_fma, proven per (M, n) at create): 1 = ONE fused multiply-add,
+        2 = one fma that also subtracts the 128 plus the add back (output layer only), 0 = the two-step form."""
+        return [int(_lib.lib().sesrq_layer_one_fma(self._h, k)) for k in range(self.bundle.L)]
 
     def layer_engines(self):
         return [(_lib.lib().sesrq_layer_engine(self._h, k) or b"").decode() for k in range(self.bundle.L)]

@@ -41,6 +41,21 @@ def one_fma_verdict(M: int, n: int):
     return first is None, first
 
 
+def single_rounding_verdict(M: int, n: int) -> bool:
+    """The output layer's second candidate: v = fl(s*M*2^-n - 128) with ONE rounding (exact value in float64), then + 128."""
+    if M == 0 or 3 * M >= (1 << 18):
+        return False
+    scale = M * 2.0 ** -n
+    lim = (1 << 22) - 1
+    lo, hi = max(-lim, int(np.floor(-2.0 / scale))), min(lim, int(np.ceil(258.0 / scale)))
+    s = np.arange(lo, hi + 1, dtype=np.int64)
+    tp = (s * M).astype(np.float32) * np.float32(2.0 ** -n)
+    ref = np.clip(np.rint(tp + np.float32(-128.0)), -128, 127) + 128
+    exact = (s * M).astype(np.float64) * 2.0 ** -n - 128.0          # < 2^40 * 2^-n: exact in float64
+    one = np.clip(np.rint(exact.astype(np.float32) + np.float32(128.0)), 0, 255)
+    return bool(np.all(ref == one))
+
+
 def test_shift_up_to_17_can_never_fail():
     """t' < 64 lies on the 2^-n grid (s*M < 2^23 is exact), so t' - 128 is exact for n <= 17: the two forms are the same number."""
     rng = np.random.default_rng(5)
@@ -74,7 +89,10 @@ def expected_flags(net: O.Net):
     for k, l in enumerate(net.layers):
         zt = net.zero[L] if k == L - 1 else net.zero[1 if k == 0 else k + 1]
         # the residual-merging layer L-2: its first requant goes into the fixed -128 domain of ic, whatever the zero points
-        out.append(bool((k == L - 2 or zt == -128) and one_fma_verdict(l.M, l.n)[0]))
+        f = 1 if ((k == L - 2 or zt == -128) and one_fma_verdict(l.M, l.n)[0]) else 0
+        if f == 0 and k == L - 1 and zt == -128 and single_rounding_verdict(l.M, l.n):
+            f = 2                                                       # output layer: the single-rounding form
+        out.append(f)
     return out
 
 
