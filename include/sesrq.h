@@ -120,6 +120,10 @@ int sesrq_fast_division_proven(const sesrq_net *net);
  * first requant (into the fixed -128 domain of ic, quan_func.py:250).  2 (output layer only): the one-fma form failed, but one fma
  * that also subtracts the 128 (a single rounding of s * M * 2^-n - 128) followed by the add of 128 is proven identical: that form runs.  No reference counterpart. */
 int sesrq_layer_one_fma(const sesrq_net *net, int k);
+/* The proof behind it as a host function of the requant constants alone (no device, no net): 1 = the one-fma form is
+ * bit-identical to clamp8(rint(fl(fl(s * M) * 2^-n - 128))) for every accumulator value s, 2 = (output_layer != 0 only) it is
+ * not, but the single-rounding form is, 0 = neither.  No reference counterpart. */
+int sesrq_requant_form(uint32_t M, uint32_t n, int output_layer);
 
 /* Bytes of device workspace sesrq_forward needs for N frames of H x W (caller-owned). */
 size_t sesrq_workspace_bytes(const sesrq_net *net, int N, int H, int W);

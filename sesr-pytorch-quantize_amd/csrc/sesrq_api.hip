@@ -379,9 +379,8 @@ int sesrq_create(const sesrq_net_desc *d, const sesrq_options *opts, sesrq_net *
             static const int knob = env_knob("SESRQ_DIRECT", 1, 0, 1);
             const int zt = (k == L - 1) ? d->zero[L] : d->zero[(k == 0) ? 1 : k + 1];
             // the residual-merging layer L-2: its FIRST requant, into the fixed -128 domain of ic (quan_func.py:250), whatever the zero points
-            a.direct = (knob && (k == L - 2 || zt == -128) && prove_direct_requant(l.M, l.n)) ? 1 : 0;
-            // the output layer's second choice (LastStore, FASTD 2x): one fma that also subtracts the 128, and the add back
-            if (knob && !a.direct && k == L - 1 && zt == -128 && prove_single_requant(l.M, l.n)) a.direct = 2;
+            // (the output layer has a second choice, form 2 -- LastStore, FASTD 2x: one fma that also subtracts the 128, and the add back)
+            a.direct = (knob && (k == L - 2 || zt == -128)) ? sesrq_requant_form(l.M, l.n, k == L - 1) : 0;
             a.Cs = a.Cd - 128.f;
         }
         a.Mres = (float)d->M_res; a.shres = ldexpf(1.0f, -(int)d->n_res);
@@ -726,6 +725,12 @@ int sesrq_requant_const(double r, int data_bit, int shift_max, uint32_t *M, uint
     *M = (uint32_t)(long long)trunc(ldexp(r, sh));
     *n = (uint32_t)sh;
     if (sh < 0) { set_error("sesrq_requant_const: multiplier >= 2^data_bit is not representable"); return 1; }
+    return 0;
+}
+
+int sesrq_requant_form(uint32_t M, uint32_t n, int output_layer) {
+    if (prove_direct_requant(M, n)) return 1;
+    if (output_layer && prove_single_requant(M, n)) return 2;
     return 0;
 }
 

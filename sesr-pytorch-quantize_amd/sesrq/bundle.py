@@ -79,6 +79,13 @@ class Bundle:
 
 
 # ---- load-time derivation through the library's host-scalar entry points -----------------
+def requant_form(M: int, n: int, output_layer: bool = False) -> int:
+    """Which reduced form of the requant into a -128 domain is bit-identical for (M, n) (sesrq_requant_form, a host-side
+    proof over every accumulator value): 1 = one fma, 2 = one fma that also subtracts the 128 + the add back (output layer
+    only), 0 = neither (the kernels keep the two-step form)."""
+    return int(_lib.lib().sesrq_requant_form(int(M), int(n), 1 if output_layer else 0))
+
+
 def requant_const(r: float, data_bit: int = 16, shift_max: int = 32):
     M, n = C.c_uint32(), C.c_uint32()
     _lib.check(_lib.lib().sesrq_requant_const(float(r), data_bit, shift_max, C.byref(M), C.byref(n)), ValueError)

@@ -83,6 +83,30 @@ def test_the_check_is_not_vacuous():
 PARAM_FILES = [f for f in golden_files("*.npz") if not f.endswith((".params.npz", "tables.npz", ".stimtxt.npz"))]
 
 
+def test_host_proof_equals_numpy_restatement():
+    """sesrq_requant_form (the proof sesrq_create runs; a host function, no device) against the numpy restatement: every (M, n)
+    of the golden bundles, the counter-example range, and a seeded sample of 16-bit multipliers with the shifts calibration gives."""
+    import sesrq
+    pairs = set()
+    for path in PARAM_FILES:
+        fx, meta = load_fixture(path)
+        net = O.net_from_fixture(fx)
+        pairs |= {(l.M, l.n) for l in net.layers}
+    pairs |= {(M, 24) for M in range(40000, 40040)}
+    rng = np.random.default_rng(11)
+    pairs |= {(int(rng.integers(1 << 15, 1 << 16)), int(rng.integers(18, 27))) for _ in range(60)}
+    forms = {0: 0, 1: 0, 2: 0}
+    for M, n in sorted(pairs):
+        one = one_fma_verdict(M, n)[0]
+        want_hidden = 1 if one else 0
+        want_out = 1 if one else (2 if single_rounding_verdict(M, n) else 0)
+        assert sesrq.requant_form(M, n) == want_hidden, (M, n)
+        assert sesrq.requant_form(M, n, output_layer=True) == want_out, (M, n)
+        forms[want_out] += 1
+    assert forms[1] > 0 and forms[2] > 0, forms
+    assert sesrq.requant_form(0, 20) == 0 and sesrq.requant_form(1 << 17, 20) == 0          # outside the biased form's own range
+
+
 def expected_flags(net: O.Net):
     L = len(net.layers)
     out = []
