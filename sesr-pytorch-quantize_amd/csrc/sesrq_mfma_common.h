@@ -16,6 +16,9 @@ typedef float v2f __attribute__((ext_vector_type(2)));
                                   four rows, but four times the store / load instructions: first layer 18.9 -> 20.0 us, trio 37.3 -> 39.7 us,
                                   14.45 k -> 14.1 k frames/s.  Not used. */
 #endif
+#ifndef SESRQ_LUT_BYTES
+#define SESRQ_LUT_BYTES 1     /* A/B knob (one-fma residual merge): 0 = med3 + rounding-constant add, address = float bits + rc byte */
+#endif
 #ifndef SESRQ_U8
 #define SESRQ_U8 1      /* A/B knob: 0 = med3 + magic add + perm epilogue everywhere (round_pack), 1 = round_pack_u8 where every zero point is -128 */
 #endif
@@ -219,7 +222,8 @@ __device__ __forceinline__ unsigned epi_preres(const int s[4], unsigned rcword, 
 // ONE_FMA (prove_direct_requant for this layer's (M, n)): w = fl(s * M) * 2^-n out of one fma, ic + 128 = rint(clamp(w, 0, 255)) --
 // the "- 128" moves from the requant into the rounding constant (lut_magic - 128): one pk_fma per two values less.
 template <bool BIASED, bool ONE_FMA = false, class AT>
-__device__ __forceinline__ unsigned epi_preres_lut(const int s[4], unsigned rcword, const AT &a, float lut_magic) {
+__device__ __forceinline__ unsigned epi_preres_lut(const int s[4], unsigned rcword, const AT &a, float lut_magic,
+                                                   const unsigned char __attribute__((address_space(3))) *lut = nullptr) {
     typedef const unsigned char __attribute__((address_space(3))) *lds_u8_t;
     v2f v01, v23;
     v2f c01, c23;
@@ -231,10 +235,31 @@ __device__ __forceinline__ unsigned epi_preres_lut(const int s[4], unsigned rcwo
         const v2f y23 = {__builtin_bit_cast(float, s[2]), __builtin_bit_cast(float, s[3])};
         v01 = __builtin_elementwise_fma(y01, M2, c2);
         v23 = __builtin_elementwise_fma(y23, M2, c2);
+#if SESRQ_LUT_BYTES
+        // ic + 128 as four bytes of one word (cvt_pk_u8: clamp, rounding and insertion in one instruction per value), rc + 128 by one
+        // xor per word; u = the sum of two unsigned bytes (v_add_u32_sdwa, BYTE_k + BYTE_k) IS the table index, the table's LDS address
+        // rides in the read's offset field: 4 cvt + 1/4 xor instead of 4 med3 + 2 pk_add per four values
+        unsigned icw = __builtin_amdgcn_cvt_pk_u8_f32(v01[0], 0, 0u);
+        icw = __builtin_amdgcn_cvt_pk_u8_f32(v01[1], 1, icw);
+        icw = __builtin_amdgcn_cvt_pk_u8_f32(v23[0], 2, icw);
+        icw = __builtin_amdgcn_cvt_pk_u8_f32(v23[1], 3, icw);
+        const unsigned rcu = rcword ^ 0x80808080u;
+        unsigned u0, u1, u2, u3;      // (inline asm: hipcc builds v_bfe + v_add3 out of the C form; the operands are plain VALU results)
+        asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:BYTE_0" : "=v"(u0) : "v"(icw), "v"(rcu));
+        asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:BYTE_1" : "=v"(u1) : "v"(icw), "v"(rcu));
+        asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_2 src1_sel:BYTE_2" : "=v"(u2) : "v"(icw), "v"(rcu));
+        asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_3 src1_sel:BYTE_3" : "=v"(u3) : "v"(icw), "v"(rcu));
+        __builtin_assume(u0 < 511u); __builtin_assume(u1 < 511u); __builtin_assume(u2 < 511u); __builtin_assume(u3 < 511u);      // so the table's base folds into the reads' offset field
+        typedef unsigned short v2us_ __attribute__((ext_vector_type(2)));
+        const v2us_ x_ = {(unsigned short)lut[u0], (unsigned short)lut[u2]};
+        const v2us_ y_ = {(unsigned short)lut[u1], (unsigned short)lut[u3]};
+        return __builtin_bit_cast(unsigned, x_) | (__builtin_bit_cast(unsigned, y_) << 8);
+#else
         const float m128 = lut_magic - 128.f;                  // MAGIC + 128 + lut_addr (exact): low 16 bits of c = lut_addr + (ic + 128) + 128
         const v2f mg = {m128, m128};
         c01 = (v2f){med3(v01[0], 0.f, 255.f), med3(v01[1], 0.f, 255.f)}; c23 = (v2f){med3(v23[0], 0.f, 255.f), med3(v23[1], 0.f, 255.f)};
         c01 = c01 + mg; c23 = c23 + mg;
+#endif
     } else {
         requant4<BIASED>(s, a.Mf, a.sh, -128.f, v01, v23);
         const v2f mg = {lut_magic, lut_magic};                 // MAGIC + 256 + lut_addr: the low 16 bits of c are lut_addr + (ic + 256)

@@ -41,7 +41,7 @@ constexpr int TR = TH + 2;        // rows per LDS window
 constexpr int OOB = (int)0x80000000;
 constexpr int TRIO_WIN = TR * TP + 2;      // pixels per LDS window (+ 2: lane group 3 over-reads one pixel)
 constexpr int TRIO_LUT_I4 = 32;               // 512-byte table of the residual merge behind the three windows
-constexpr int TRIO_LDS_BYTES = (3 * TRIO_WIN + TRIO_LUT_I4) * 16;
+constexpr int TRIO_LDS_BYTES = 3 * TRIO_WIN * 16;      // dynamic part (the windows); the table is static LDS, TRIO_LUT_I4 * 16 bytes more
 
 struct TrioStage {
     static constexpr int NIT = 3;         // 660 pixels (cold: 10 rows) or 528 (steady: 8 rows) over 256 threads
@@ -104,10 +104,13 @@ struct TrioEpiC {           // the field names the shared epilogues read
 template <int EPI_C, int U8>
 __global__ __launch_bounds__(256) void mfma_trio_kernel(const TrioArgs a) {
     extern __shared__ int4 trio_lds[];             // dynamic: the launch pads the size so that exactly `occ` workgroups fit a CU
-    int4 *bufI = trio_lds, *bufA = trio_lds + TRIO_WIN, *bufB = trio_lds + 2 * TRIO_WIN;
+    // the residual merge's table is the kernel's only STATIC LDS object: its address is the compile-time constant 0, so a table index
+    // IS an LDS address (no base to add per lookup); the three windows are the dynamic part behind it
+    __shared__ int4 trio_lut[TRIO_LUT_I4];
+    int4 *lutp = trio_lut, *bufI = trio_lds, *bufA = bufI + TRIO_WIN, *bufB = bufI + 2 * TRIO_WIN;
     constexpr bool LUT = EPI_C == EPI_PRERES && SESRQ_TRIO_LUT;
     // MAGIC + 256 + the table's LDS byte address (exact: < 2^24); see epi_preres_lut
-    const float lut_magic = MAGIC + 256.f + (float)(unsigned)(size_t)(const __attribute__((address_space(3))) void *)(trio_lds + 3 * TRIO_WIN);
+    const float lut_magic = MAGIC + 256.f + (float)(unsigned)(size_t)(const __attribute__((address_space(3))) void *)lutp;
     const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, n = l & 15, g = l >> 4;
     const int n_img = blockIdx.z;
     const int x0 = blockIdx.x * TV - 2;              // frame column of computed column 0
@@ -121,7 +124,7 @@ __global__ __launch_bounds__(256) void mfma_trio_kernel(const TrioArgs a) {
     const int y_end = a.run_unit * (int)(((long long)(blockIdx.y + 1) * units_total) / gridDim.y);
     if (y_begin >= y_end) return;
     if constexpr (LUT) {           // visible to every wave long before the first residual merge (barriers of the cold start)
-        if (threadIdx.x < 128) reinterpret_cast<int *>(trio_lds + 3 * TRIO_WIN)[threadIdx.x] = a.merge_lut[threadIdx.x];
+        if (threadIdx.x < 128) reinterpret_cast<int *>(lutp)[threadIdx.x] = a.merge_lut[threadIdx.x];
     }
 
     const int c = 16 * w + n, gx = x0 + c;
@@ -217,7 +220,8 @@ __global__ __launch_bounds__(256) void mfma_trio_kernel(const TrioArgs a) {
                 unsigned rcw[4] = {rv[0], rv[1], rv[2], rv[3]}, wq[4];
                 transpose4(rcw);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) wq[r] = epi_preres_lut<true, (U8 & 4) != 0>(s4[r], rcw[r], ec, lut_magic);
+                for (int r = 0; r < 4; ++r) wq[r] = epi_preres_lut<true, (U8 & 4) != 0>(s4[r], rcw[r], ec, lut_magic,
+                                                                                      (const unsigned char __attribute__((address_space(3))) *)lutp);
                 store_rows4(io.out, io, y4, wq);
             } else {
                 emit_rows4<EPI_C, false, true, (U8 & 4) ? 2 : (U8 & 1)>(s4, ec, io, y4, a.l[2].zlo);
@@ -300,7 +304,7 @@ static void launch_trio_k(K kern, TrioArgs a, hipStream_t st) {
     // rows per partition unit (4 / 8, 0 = by run length)
     static const int occ = env_knob("SESRQ_TRIO_OCC", 4, 3, 4), unit_knob = env_knob("SESRQ_TRIO_UNIT", 0, 4, 8);
     const int num_cu = device_cu_count();
-    const int lds = std::max(TRIO_LDS_BYTES, (160 * 1024 / occ) & ~1023);      // exactly occ workgroups per 160 KiB
+    const int lds = std::max(TRIO_LDS_BYTES, ((160 * 1024 / occ) & ~1023) - TRIO_LUT_I4 * 16);      // static + dynamic: exactly occ workgroups per 160 KiB
     const int strips = (a.W + TV - 1) / TV, steps = (a.H + TH - 1) / TH;
     long long k = (a.wg_budget > 0 ? (long long)a.wg_budget : (long long)occ * num_cu) / ((long long)strips * a.N);
     k = std::max(1LL, std::min<long long>(k, steps));                     // a run is at least one full step on average
