@@ -984,6 +984,9 @@ static void launch(K kern, ConvArgs a, hipStream_t st, int tile_h = MTH) {
         }
         blocks_per_cu = it->second;
     }
+    // experiment knobs (read once): a budget of its own for the first layer (tile height 12) / the other per-layer kernels, when the net has one
+    static const int wg_f5 = env_knob("SESRQ_WG_F5", 0, 1, 1 << 16), wg_h = env_knob("SESRQ_WG_H5", 0, 1, 1 << 16);
+    if (a.wg_budget > 0) { if (tile_h == F5_TH && wg_f5 > 0) a.wg_budget = wg_f5; else if (tile_h != F5_TH && wg_h > 0) a.wg_budget = wg_h; }
     const int strips = (a.W + MTW - 1) / MTW, row_tiles = (a.H + tile_h - 1) / tile_h;
     long long k = (a.wg_budget > 0 ? (long long)a.wg_budget : (long long)blocks_per_cu * num_cu) / ((long long)strips * a.N);
     k = std::max(1LL, std::min<long long>(k, row_tiles));

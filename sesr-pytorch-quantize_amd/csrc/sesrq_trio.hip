@@ -306,6 +306,8 @@ static void launch_trio_k(K kern, TrioArgs a, hipStream_t st) {
     const int num_cu = device_cu_count();
     const int lds = std::max(TRIO_LDS_BYTES, ((160 * 1024 / occ) & ~1023) - TRIO_LUT_I4 * 16);      // static + dynamic: exactly occ workgroups per 160 KiB
     const int strips = (a.W + TV - 1) / TV, steps = (a.H + TH - 1) / TH;
+    static const int wg_trio = env_knob("SESRQ_WG_TRIO", 0, 1, 1 << 16);      // experiment knob: a budget of its own for the trio, when the net has one
+    if (a.wg_budget > 0 && wg_trio > 0) a.wg_budget = wg_trio;
     long long k = (a.wg_budget > 0 ? (long long)a.wg_budget : (long long)occ * num_cu) / ((long long)strips * a.N);
     k = std::max(1LL, std::min<long long>(k, steps));                     // a run is at least one full step on average
     a.chunk_steps = (int)((steps + k - 1) / k);
