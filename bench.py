@@ -317,7 +317,8 @@ def main():
                                           "reference checkpoint, calibrated by this package (parity unpinned)" if "bundle" in f else
                                           "reference checkpoint, quantised and calibrated by the reference") + f" ({f})" for f in fixtures],
                              "sharding": f"frames over {world} rank(s), contiguous blocks, no collective",
-                             "launch_plan": [[names[f], c] for f, c in plan], "engines": [e.layer_engines() for e in engines]},
+                             "launch_plan": [[names[f], c] for f, c in plan], "engines": [e.layer_engines() for e in engines],
+                             "requant_forms": [e.one_fma_layers() for e in engines]},      # per layer: 1 / 2 = a load-time proof let the kernels run a reduced form
                   "roofline": roofline, "cpu_baseline": cpu, "e2e": e2e, "parity": parity}
     grp.close()
     if result is not None:
