@@ -21,6 +21,9 @@ typedef unsigned v2u __attribute__((ext_vector_type(2)));
 #define K_XOR(x) asm volatile("v_xor_b32 %0, %0, %1" : "+v"(x) : "v"(a));
 #define K_MOV64(p) asm volatile("v_mov_b64 %0, %1" : "=v"(p) : "v"(a2));
 #define K_PKFMA_S(p) asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(p) : "s"(a2s), "v"(b2));
+#define K_CNDMASK64(x) asm volatile("v_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(x) : "v"(a), "s"(m64));
+#define K_ANDS(x) asm volatile("v_and_b32 %0, %1, %0" : "+v"(x) : "s"(a));
+#define K_AND(x) asm volatile("v_and_b32 %0, %1, %0" : "+v"(x) : "v"(a));
 #define K_MAX(x) asm volatile("v_max_f32 %0, %0, %1" : "+v"(x) : "v"(a));
 #define K_PERM(x) asm volatile("v_perm_b32 %0, %0, %1, %2" : "+v"(x) : "v"(a), "v"(b));
 #define K_PERM_S(x) asm volatile("v_perm_b32 %0, %0, %1, %2" : "+v"(x) : "v"(a), "s"(b));
@@ -44,7 +47,7 @@ typedef unsigned v2u __attribute__((ext_vector_type(2)));
     __global__ void NAME(float *out, int iters, float a, float b) {                                  \
         float x0 = threadIdx.x, x1 = x0 + 1, x2 = x0 + 2, x3 = x0 + 3, x4 = x0 + 4, x5 = x0 + 5, x6 = x0 + 6, x7 = x0 + 7, y0 = 3.f; \
         v2f p0 = {x0, x1}, p1 = {x2, x3}, p2 = {x4, x5}, p3 = {x6, x7};                               \
-        const v2f a2 = {a, a}, b2 = {b, b}; const v2f a2s = {a, b};                                 \
+        const v2f a2 = {a, a}, b2 = {b, b}; const v2f a2s = {a, b}; const unsigned long long m64 = 0x5555555555555555ull + (unsigned long long)iters;                                 \
         for (int i = 0; i < iters; ++i) { BODY }                                                     \
         out[blockIdx.x * blockDim.x + threadIdx.x] = x0 + x1 + x2 + x3 + x4 + x5 + x6 + x7 + y0 + p0[0] + p0[1] + p1[0] + p1[1] + p2[0] + p2[1] + p3[0] + p3[1] + a2[0] + b2[0]; \
     }                                                                                                 \
@@ -57,7 +60,7 @@ KERNEL(k_sdwa, REP8(K_SDWA), 8) KERNEL(k_swap32, REP8(K_SWAP32), 8) KERNEL(k_swa
 KERNEL(k_cndmask, REP8(K_CNDMASK), 8) KERNEL(k_pkfma, REP4P(K_PKFMA) REP4P(K_PKFMA), 8) KERNEL(k_pkadd, REP4P(K_PKADD) REP4P(K_PKADD), 8)
 KERNEL(k_pkmul, REP4P(K_PKMUL) REP4P(K_PKMUL), 8) KERNEL(k_pkmov, REP4P(K_PKMOV) REP4P(K_PKMOV), 8)
 KERNEL(k_med3_ss, REP8(K_MED3_SS), 8) KERNEL(k_med3i_s, REP8(K_MED3I_S), 8) KERNEL(k_fmac, REP8(K_FMAC), 8) KERNEL(k_mul, REP8(K_MUL), 8) KERNEL(k_muls, REP8(K_MULS), 8)
-KERNEL(k_xor, REP8(K_XOR), 8) KERNEL(k_mov64, REP4P(K_MOV64) REP4P(K_MOV64), 8) KERNEL(k_pkfma_s, REP4P(K_PKFMA_S) REP4P(K_PKFMA_S), 8)
+KERNEL(k_cndmask64, REP8(K_CNDMASK64), 8) KERNEL(k_ands, REP8(K_ANDS), 8) KERNEL(k_and, REP8(K_AND), 8) KERNEL(k_xor, REP8(K_XOR), 8) KERNEL(k_mov64, REP4P(K_MOV64) REP4P(K_MOV64), 8) KERNEL(k_pkfma_s, REP4P(K_PKFMA_S) REP4P(K_PKFMA_S), 8)
 template <typename K>
 static void run(const char *name, K kern, int n, float *d, double ref_ns) {
     hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
@@ -87,6 +90,6 @@ int main() {
     RUN(k_sdwa, "v_add_u32_sdwa"); RUN(k_swap32, "v_permlane32_swap"); RUN(k_swap16, "v_permlane16_swap"); RUN(k_mov, "v_mov_b32");
     RUN(k_cndmask, "v_cndmask_b32"); RUN(k_pkfma, "v_pk_fma_f32"); RUN(k_pkadd, "v_pk_add_f32"); RUN(k_pkmul, "v_pk_mul_f32"); RUN(k_pkmov, "v_pk_mov_b32");
     RUN(k_med3_ss, "v_med3_f32 (2 sgpr same)"); RUN(k_med3i_s, "v_med3_i32 (1 sgpr)"); RUN(k_fmac, "v_fmac_f32"); RUN(k_mul, "v_mul_f32"); RUN(k_muls, "v_mul_f32 (sgpr)");
-    RUN(k_xor, "v_xor_b32"); RUN(k_mov64, "v_mov_b64"); RUN(k_pkfma_s, "v_pk_fma_f32 (sgpr pair)");
+    RUN(k_cndmask64, "v_cndmask_b32 (sgpr pair mask)"); RUN(k_ands, "v_and_b32 (sgpr)"); RUN(k_and, "v_and_b32"); RUN(k_xor, "v_xor_b32"); RUN(k_mov64, "v_mov_b64"); RUN(k_pkfma_s, "v_pk_fma_f32 (sgpr pair)");
     return 0;
 }
