@@ -110,7 +110,7 @@ struct LastStore {
             w = __builtin_amdgcn_cvt_pk_u8_f32(w01[1], 1, w);
             w = __builtin_amdgcn_cvt_pk_u8_f32(w23[0], 2, w);
             if constexpr (NV == 4) w = __builtin_amdgcn_cvt_pk_u8_f32(w23[1], 3, w);
-            w ^= 0x80808080u;
+            w = flip80(w);
             const int so = __builtin_amdgcn_readfirstlane(row_ok ? gy * (FAST * FAST * a.W) : 0x7fff0000);
             if constexpr (NV == 3) {
                 static_assert(FAST == 2, "three real rows per lane group: the PixelShuffle(2) pair map only");

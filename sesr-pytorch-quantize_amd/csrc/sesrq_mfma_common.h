@@ -99,6 +99,14 @@ __device__ __forceinline__ float in_vgpr(float x) {
     return r;
 }
 
+// 0x80808080 (u8 <-> two's complement, four bytes at once) as a VGPR operand: v_xor with a literal costs 2.0 ns per wave, with a
+// VGPR 1.4 (tools/op_cost_probe.hip); the asm is pure, so one v_mov per call site, hoisted out of the row loops
+__device__ __forceinline__ unsigned flip80(unsigned w) {
+    unsigned k;
+    asm("s_nop 1\n\tv_mov_b32 %0, 0x80808080" : "=v"(k));
+    return w ^ k;
+}
+
 // low bytes of four words -> one word
 __device__ __forceinline__ unsigned pack_lo_bytes(unsigned y0, unsigned y1, unsigned y2, unsigned y3) {
     const unsigned w01 = __builtin_amdgcn_perm(y1, y0, 0x0c0c0400u);
@@ -151,7 +159,7 @@ __device__ __forceinline__ unsigned round_pack_u8(v2f v01, v2f v23) {
     w = __builtin_amdgcn_cvt_pk_u8_f32(v01[1], 1, w);
     w = __builtin_amdgcn_cvt_pk_u8_f32(v23[0], 2, w);
     w = __builtin_amdgcn_cvt_pk_u8_f32(v23[1], 3, w);
-    return w ^ 0x80808080u;
+    return flip80(w);
 }
 
 // ---- epilogues (AT = any struct with the ConvArgs field names Mf, sh, z_next, Mres, shres, z_merge) ----
@@ -175,7 +183,7 @@ __device__ __forceinline__ unsigned epi_mid(const int s[4], const AT &a, float z
         w = __builtin_amdgcn_cvt_pk_u8_f32(v01[1], 1, w);
         w = __builtin_amdgcn_cvt_pk_u8_f32(v23[0], 2, w);
         w = __builtin_amdgcn_cvt_pk_u8_f32(v23[1], 3, w);
-        return w ^ 0x80808080u;
+        return flip80(w);
     }
     if constexpr (U8 == 1) {
         requant4<BIASED>(s, a.Mf, a.sh, -128.f, v01, v23);
@@ -243,7 +251,7 @@ __device__ __forceinline__ unsigned epi_preres_lut(const int s[4], unsigned rcwo
         icw = __builtin_amdgcn_cvt_pk_u8_f32(v01[1], 1, icw);
         icw = __builtin_amdgcn_cvt_pk_u8_f32(v23[0], 2, icw);
         icw = __builtin_amdgcn_cvt_pk_u8_f32(v23[1], 3, icw);
-        const unsigned rcu = rcword ^ 0x80808080u;
+        const unsigned rcu = flip80(rcword);
         unsigned u0, u1, u2, u3;      // (inline asm: hipcc builds v_bfe + v_add3 out of the C form; the operands are plain VALU results)
         asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:BYTE_0" : "=v"(u0) : "v"(icw), "v"(rcu));
         asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:BYTE_1" : "=v"(u1) : "v"(icw), "v"(rcu));

@@ -100,7 +100,10 @@ struct TrioEpiC {           // the field names the shared epilogues read
 
 // U8, a bit mask: 1 = every zero point of the three epilogues is -128 (the launch checks): round_pack_u8 (sesrq_mfma_common.h);
 // 2 = the requants of layers a and b passed prove_direct_requant: the one-fma form of epi_mid; 4 = so did the third layer's
-// (residual merge: its first requant, into the fixed -128 domain of ic).  Instances: 0, 1, 3, 7
+// (residual merge: its first requant, into the fixed -128 domain of ic); 8 = the residual operand IS the trio's input tensor (the
+// 5-conv nets: layer 0's output, zero[1] == -128): it is read out of the input window in LDS, already in compute layout (word g of pixel
+// n), instead of being loaded again from global memory and transposed (2 loads + 8 v_permlane*_swap per step, and 33 MB per 1080p
+// frame off the L2 / MALL).  Instances: 0, 1, 3, 7, 15
 template <int EPI_C, int U8>
 __global__ __launch_bounds__(256) void mfma_trio_kernel(const TrioArgs a) {
     extern __shared__ int4 trio_lds[];             // dynamic: the launch pads the size so that exactly `occ` workgroups fit a CU
@@ -109,6 +112,7 @@ __global__ __launch_bounds__(256) void mfma_trio_kernel(const TrioArgs a) {
     __shared__ int4 trio_lut[TRIO_LUT_I4];
     int4 *lutp = trio_lut, *bufI = trio_lds, *bufA = bufI + TRIO_WIN, *bufB = bufI + 2 * TRIO_WIN;
     constexpr bool LUT = EPI_C == EPI_PRERES && SESRQ_TRIO_LUT;
+    constexpr bool RCW = LUT && (U8 & 8) != 0;
     // MAGIC + 256 + the table's LDS byte address (exact: < 2^24); see epi_preres_lut
     const float lut_magic = MAGIC + 256.f + (float)(unsigned)(size_t)(const __attribute__((address_space(3))) void *)lutp;
     const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, n = l & 15, g = l >> 4;
@@ -218,7 +222,7 @@ __global__ __launch_bounds__(256) void mfma_trio_kernel(const TrioArgs a) {
             if constexpr (LUT) {
                 const v4u rv = rcp[y4 / 4];
                 unsigned rcw[4] = {rv[0], rv[1], rv[2], rv[3]}, wq[4];
-                transpose4(rcw);
+                if constexpr (!RCW) transpose4(rcw);      // RCW: read from the window in compute layout
 #pragma unroll
                 for (int r = 0; r < 4; ++r) wq[r] = epi_preres_lut<true, (U8 & 4) != 0>(s4[r], rcw[r], ec, lut_magic,
                                                                                       (const unsigned char __attribute__((address_space(3))) *)lutp);
@@ -227,6 +231,19 @@ __global__ __launch_bounds__(256) void mfma_trio_kernel(const TrioArgs a) {
                 emit_rows4<EPI_C, false, true, (U8 & 4) ? 2 : (U8 & 1)>(s4, ec, io, y4, a.l[2].zlo);
             }
         }
+    };
+    // RCW: the residual operand of frame row (window position pos) of this lane's output pixel, straight from the input window
+    auto rc_win = [&](int pos) __attribute__((always_inline)) { return (unsigned)reinterpret_cast<const int *>(bufI)[pos * TP * 4 + wrcol]; };
+    // output rows Y .. Y+NR-1 <- the carried word (row Y: the previous window's position 7) and positions 0 .. NR-2; position NR-1 is
+    // row Y+NR, the next step's first.  Called while bufI still holds rows Y+1 .. Y+10 (before the step's first barrier).
+    unsigned rcc = 0;
+    auto rc_from_window = [&](auto NRC, v4u (&rcp)[2]) __attribute__((always_inline)) {
+        constexpr int NR = decltype(NRC)::value;
+        unsigned t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int i = 0; i < NR; ++i) t[i] = rc_win(i);
+        rcp[0] = (v4u){rcc, t[0], t[1], t[2]};
+        if constexpr (NR == 8) { rcp[1] = (v4u){t[3], t[4], t[5], t[6]}; rcc = t[7]; }
     };
     using std::integral_constant;
     auto shift = [&](int4 *win) __attribute__((always_inline)) {      // rows TH, TH+1 of a window -> rows 0, 1
@@ -246,6 +263,7 @@ __global__ __launch_bounds__(256) void mfma_trio_kernel(const TrioArgs a) {
         st.load<true>(a, Y + 1);
         st.store<true>(bufI, a.pad_in, tid);
         __syncthreads();
+        if constexpr (RCW) rcc = rc_win(TH - 1);                // frame row y_begin = position 7 of the cold-start window (rows y_begin-7 ..)
         st.load<false>(a, Y + TH + 3);
         inner(IC0(), IC4(), IC8(), bufI, bufA, Y + 2, std::true_type());
         int4 shI = make_int4(0, 0, 0, 0);
@@ -263,6 +281,8 @@ __global__ __launch_bounds__(256) void mfma_trio_kernel(const TrioArgs a) {
         const bool more = Y + TH < y_end;                        // another step (full or half) follows
         if (more) st.load<false>(a, Y + TH + 3);                 // its new input rows, consumed after the first barrier
         shift(bufB);                                             // layer-b rows Y-1, Y (phase c of the previous step is done)
+        v4u rcp[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
+        if constexpr (RCW) rc_from_window(IC8(), rcp);           // bufI = rows Y+1 .. Y+10 until the first barrier
         const bool nopad = SESRQ_TRIO_NOPAD && strip_in && (Y + TH + 2 <= a.H);      // wave-uniform: rows Y+1 .. Y+9, all 64 columns inside
         if (nopad) inner(IC0(), IC0(), IC8(), bufI, bufA, Y + 2, std::false_type());
         else inner(IC0(), IC0(), IC8(), bufI, bufA, Y + 2, std::true_type());
@@ -273,8 +293,7 @@ __global__ __launch_bounds__(256) void mfma_trio_kernel(const TrioArgs a) {
             if (tid < 2 * TP) bufI[tid] = shI;
             st.store<false>(bufI, a.pad_in, tid);
         }
-        v4u rcp[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
-        rc_fetch(IC8(), Y, rcp);                                 // in flight during phase b
+        if constexpr (!RCW) rc_fetch(IC8(), Y, rcp);             // in flight during phase b
         if (nopad) inner(IC1(), IC0(), IC8(), bufA, bufB, Y + 1, std::false_type());
         else inner(IC1(), IC0(), IC8(), bufA, bufB, Y + 1, std::true_type());
         __syncthreads();
@@ -284,10 +303,11 @@ __global__ __launch_bounds__(256) void mfma_trio_kernel(const TrioArgs a) {
     }
     if (Y < y_end) {                                             // the closing half step: output rows Y .. Y+3
         shift(bufB);
+        v4u rcp[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
+        if constexpr (RCW) rc_from_window(IC4(), rcp);
         inner(IC0(), IC0(), IC4(), bufI, bufA, Y + 2, std::true_type());
         __syncthreads();
-        v4u rcp[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
-        rc_fetch(IC4(), Y, rcp);
+        if constexpr (!RCW) rc_fetch(IC4(), Y, rcp);
         inner(IC1(), IC0(), IC4(), bufA, bufB, Y + 1, std::true_type());
         __syncthreads();
         outer(IC4(), Y, rcp);
@@ -326,8 +346,10 @@ int launch_trio(const TrioArgs &a, int epi_c, hipStream_t st) {
     if (!SESRQ_U8) u8 = false;                     // A/B build knob
     const bool ab = u8 && a.l[0].direct && a.l[1].direct, abc = ab && a.l[2].direct;      // one-fma requants (proof per layer)
     const int mode = abc ? 7 : (ab ? 3 : (u8 ? 1 : 0));
+    static const int rcw_knob = env_knob("SESRQ_TRIO_RCW", 1, 0, 1);
     if (epi_c == EPI_PRERES) {
-        if (mode == 7) launch_trio_k(mfma_trio_kernel<EPI_PRERES, 7>, a, st);
+        if (mode == 7 && a.rc_in == a.in && rcw_knob && SESRQ_TRIO_LUT) launch_trio_k(mfma_trio_kernel<EPI_PRERES, 15>, a, st);      // the residual operand out of the input window
+        else if (mode == 7) launch_trio_k(mfma_trio_kernel<EPI_PRERES, 7>, a, st);
         else if (mode == 3) launch_trio_k(mfma_trio_kernel<EPI_PRERES, 3>, a, st);
         else if (mode == 1) launch_trio_k(mfma_trio_kernel<EPI_PRERES, 1>, a, st);
         else launch_trio_k(mfma_trio_kernel<EPI_PRERES, 0>, a, st);
