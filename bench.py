@@ -46,7 +46,7 @@ WORKLOADS = {
 
 # Launch plan per workload: (streams, wg_budget), chosen by throughput in same-box A/Bs (tools/plan_ab.sh; profiles/README.md, round 3):
 # 1080p: 3 streams x 512 slots 14.5 k frames/s vs 2 streams x full chip 14.2 k; anything else: the round-2 plan.
-PLAN = {"sesr_x2_1080p": (3, 512)}
+PLAN = {"sesr_x2_1080p": (3, 512), "nrdm_3_540p": (3, 512), "sesr_x4_540p": (3, 512), "nrdm6_sesrx2_540p": (3, 512)}      # same-box A/Bs, profiles/README.md
 PLAN_DEFAULT = (2, 0)
 
 
@@ -88,14 +88,14 @@ def main():
     ap.add_argument("--streams", type=int, default=0,
                     help="HIP streams the steps are enqueued on round-robin (frames are independent; each stream has "
                          "its own workspace and output buffer) -- fills the launch/prologue/tail gaps between kernels.  0 = the "
-                         "workload's tuned plan (PLAN): 3 for the 1080p headline, 2 otherwise")
+                         "workload's tuned plan (PLAN): 3 for the single-frame workloads, 2 for the 32-frame batch")
     ap.add_argument("--workload", default="sesr_x2_1080p", choices=sorted(WORKLOADS))
     ap.add_argument("--engine", default="auto", choices=["auto", "dot4", "mfma"])
     ap.add_argument("--no-fuse", action="store_true", help="one launch per layer (no fused hidden trio)")
     ap.add_argument("--fuse", type=int, default=1, choices=[0, 1, 2], help="0 per layer, 1 (default) hidden trios, 2 + fused front")
     ap.add_argument("--wg-budget", type=int, default=-1,
                     help="workgroup slots a launch may fill (sesrq_options.wg_budget; 0 = one full round of the chip).  -1 = the workload's "
-                         "tuned plan (PLAN): 512 of the 1024 slots for the 1080p headline, so that kernels of three frames stay co-resident "
+                         "tuned plan (PLAN): 512 of the 1024 slots for the single-frame workloads, so that kernels of three frames stay co-resident "
                          "on every CU instead of meeting only at their tails")
     ap.add_argument("--timing-iters", type=int, default=200, help="forwards of the per-launch HIP-event timing (roofline)")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
