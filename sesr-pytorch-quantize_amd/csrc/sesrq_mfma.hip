@@ -100,12 +100,26 @@ struct LastStore {
         if constexpr (FASTD >= 10) {
             static_assert(BIASED && FAST != 0, "one-fma requant: biased sums, int8 output");
             // FASTD 2x (ConvArgs::direct == 2): the fma also subtracts the 128 (one rounding of s*M*2^-n - 128), one add brings it back
+            v2f w01, w23;
+            if constexpr (SESRQ_UNPACK) {
+                const float cv = in_vgpr(FASTD >= 20 ? a.Cs : a.Cd), mv = in_vgpr(a.Md);
+                float t[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int i = 0; i < NV; ++i) t[i] = __builtin_fmaf(__builtin_bit_cast(float, s[i]), mv, cv);
+                if constexpr (FASTD >= 20) {
+                    const float kv = in_vgpr(128.f);
+#pragma unroll
+                    for (int i = 0; i < NV; ++i) t[i] = __fadd_rn(t[i], kv);
+                }
+                w01 = (v2f){t[0], t[1]}; w23 = (v2f){t[2], t[3]};
+            } else {
             const float cv = in_vgpr(FASTD >= 20 ? a.Cs : a.Cd);
             const v2f M2 = {a.Md, a.Md}, c2 = {cv, cv};
             const v2f y01 = {__builtin_bit_cast(float, s[0]), __builtin_bit_cast(float, s[1])};
             const v2f y23 = {__builtin_bit_cast(float, s[2]), __builtin_bit_cast(float, s[NV == 4 ? 3 : 2])};
-            v2f w01 = __builtin_elementwise_fma(y01, M2, c2), w23 = __builtin_elementwise_fma(y23, M2, c2);
+            w01 = __builtin_elementwise_fma(y01, M2, c2); w23 = __builtin_elementwise_fma(y23, M2, c2);
             if constexpr (FASTD >= 20) { const float kv = in_vgpr(128.f); const v2f k = {kv, kv}; w01 = w01 + k; w23 = w23 + k; }      // a VGPR operand: 1.4 ns, a literal 2.1
+            }
             unsigned w = __builtin_amdgcn_cvt_pk_u8_f32(w01[0], 0, 0u);
             w = __builtin_amdgcn_cvt_pk_u8_f32(w01[1], 1, w);
             w = __builtin_amdgcn_cvt_pk_u8_f32(w23[0], 2, w);
@@ -559,8 +573,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SESRQ_H5_WA
 #pragma unroll
                     for (int p = 0; p < 4; ++p) {
                         const int o = y4 + (r + p * CP);
+#ifdef SESRQ_H5_FAKE64      /* throwaway timing experiment: 8-byte-aligned ds_read_b64 at (wrong) rounded-down addresses */
+                        typedef int v2ia __attribute__((ext_vector_type(2)));
+                        typedef const v2ia __attribute__((address_space(3))) *lds_apair_t;
+                        const int o8 = (o & ~1) * 4;
+                        const v2ia a0 = *(lds_apair_t)(size_t)((pb[0][0] & ~7u) + o8), a1 = *(lds_apair_t)(size_t)((pb[0][1] & ~7u) + o8);
+                        const v2ia c0 = *(lds_apair_t)(size_t)((pb[1][0] & ~7u) + o8), c1 = *(lds_apair_t)(size_t)((pb[1][1] & ~7u) + o8);
+#else
                         const v2iu a0 = *(lds_pair_t)(size_t)(pb[0][0] + 4 * o), a1 = *(lds_pair_t)(size_t)(pb[0][1] + 4 * o);
                         const v2iu c0 = *(lds_pair_t)(size_t)(pb[1][0] + 4 * o), c1 = *(lds_pair_t)(size_t)(pb[1][1] + 4 * o);
+#endif
                         const v4i b0 = {a0[0], a0[1], a1[0], a1[1]};
                         const v4i b1 = {c0[0], c0[1], c1[0], c1[1]};
                         acc[p] = mfma(A[p], b0, zero);

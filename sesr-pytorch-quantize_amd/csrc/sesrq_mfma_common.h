@@ -23,6 +23,12 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 #define SESRQ_U8 1      /* A/B knob: 0 = med3 + magic add + perm epilogue everywhere (round_pack), 1 = round_pack_u8 where every zero point is -128 */
 #endif
 
+#ifndef SESRQ_UNPACK
+#define SESRQ_UNPACK 1     /* round 4: 1 = the one-fma requants as four v_fma_f32 with all-VGPR operands instead of two v_pk_fma_f32 (tools/coissue2_probe.hip) */
+#endif
+#ifndef SESRQ_SER
+#define SESRQ_SER 0        /* experiment (round 4): 1 = a scheduling barrier behind every row: chain, then its epilogue, no interleaving with the next row's chain */
+#endif
 constexpr float MAGIC = 12582912.f;   // 1.5 * 2^23
 
 // accumulate modes
@@ -162,6 +168,22 @@ __device__ __forceinline__ unsigned round_pack_u8(v2f v01, v2f v23) {
     return flip80(w);
 }
 
+// w[i] = fma(bits(s[i]), M, c) for four biased sums: packed (two v_pk_fma_f32) or unpacked (four v_fma_f32, every operand a VGPR)
+__device__ __forceinline__ void fma4_biased(const int s[4], float Md, float Cd, float w[4]) {
+    const float cv = in_vgpr(Cd);
+#if SESRQ_UNPACK
+    const float mv = in_vgpr(Md);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) w[i] = __builtin_fmaf(__builtin_bit_cast(float, s[i]), mv, cv);
+#else
+    const v2f M2 = {Md, Md}, c2 = {cv, cv};
+    const v2f y01 = {__builtin_bit_cast(float, s[0]), __builtin_bit_cast(float, s[1])};
+    const v2f y23 = {__builtin_bit_cast(float, s[2]), __builtin_bit_cast(float, s[3])};
+    const v2f v01 = __builtin_elementwise_fma(y01, M2, c2), v23 = __builtin_elementwise_fma(y23, M2, c2);
+    w[0] = v01[0]; w[1] = v01[1]; w[2] = v23[0]; w[3] = v23[1];
+#endif
+}
+
 // ---- epilogues (AT = any struct with the ConvArgs field names Mf, sh, z_next, Mres, shres, z_merge) ----
 // U8: every zero point the epilogue adds is -128 (z_next; for the residual merge also z_merge): round_pack_u8
 
@@ -173,16 +195,12 @@ __device__ __forceinline__ unsigned epi_mid(const int s[4], const AT &a, float z
     v2f v01, v23;
     if constexpr (U8 == 2) {
         static_assert(BIASED, "one-fma requant: biased sums only");
-        const float cv = in_vgpr(a.Cd);      // see in_vgpr(): Md and Cd are neighbours in the kernel arguments
-        const v2f M2 = {a.Md, a.Md}, c2 = {cv, cv};
-        const v2f y01 = {__builtin_bit_cast(float, s[0]), __builtin_bit_cast(float, s[1])};
-        const v2f y23 = {__builtin_bit_cast(float, s[2]), __builtin_bit_cast(float, s[3])};
-        v01 = __builtin_elementwise_fma(y01, M2, c2);
-        v23 = __builtin_elementwise_fma(y23, M2, c2);
-        unsigned w = __builtin_amdgcn_cvt_pk_u8_f32(v01[0], 0, 0u);
-        w = __builtin_amdgcn_cvt_pk_u8_f32(v01[1], 1, w);
-        w = __builtin_amdgcn_cvt_pk_u8_f32(v23[0], 2, w);
-        w = __builtin_amdgcn_cvt_pk_u8_f32(v23[1], 3, w);
+        float t[4];
+        fma4_biased(s, a.Md, a.Cd, t);
+        unsigned w = __builtin_amdgcn_cvt_pk_u8_f32(t[0], 0, 0u);
+        w = __builtin_amdgcn_cvt_pk_u8_f32(t[1], 1, w);
+        w = __builtin_amdgcn_cvt_pk_u8_f32(t[2], 2, w);
+        w = __builtin_amdgcn_cvt_pk_u8_f32(t[3], 3, w);
         return flip80(w);
     }
     if constexpr (U8 == 1) {
@@ -237,12 +255,9 @@ __device__ __forceinline__ unsigned epi_preres_lut(const int s[4], unsigned rcwo
     v2f c01, c23;
     if constexpr (ONE_FMA) {
         static_assert(BIASED, "one-fma requant: biased sums only");
-        const float cv = in_vgpr(a.Cd);
-        const v2f M2 = {a.Md, a.Md}, c2 = {cv, cv};
-        const v2f y01 = {__builtin_bit_cast(float, s[0]), __builtin_bit_cast(float, s[1])};
-        const v2f y23 = {__builtin_bit_cast(float, s[2]), __builtin_bit_cast(float, s[3])};
-        v01 = __builtin_elementwise_fma(y01, M2, c2);
-        v23 = __builtin_elementwise_fma(y23, M2, c2);
+        float t[4];
+        fma4_biased(s, a.Md, a.Cd, t);
+        v01 = (v2f){t[0], t[1]}; v23 = (v2f){t[2], t[3]};
 #if SESRQ_LUT_BYTES
         // ic + 128 as four bytes of one word (cvt_pk_u8: clamp, rounding and insertion in one instruction per value), rc + 128 by one
         // xor per word; u = the sum of two unsigned bytes (v_add_u32_sdwa, BYTE_k + BYTE_k) IS the table index, the table's LDS address

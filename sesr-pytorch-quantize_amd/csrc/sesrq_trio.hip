@@ -171,9 +171,16 @@ __global__ __launch_bounds__(256) void mfma_trio_kernel(const TrioArgs a) {
         const int4 *p = src + rdcol;
         unsigned *d = reinterpret_cast<unsigned *>(dst) + wrcol;
         v4i B0 = ld_frag(p + (i0)*TP), B1 = ld_frag(p + (i0 + 1) * TP);
+        v4i Bn = ld_frag(p + (i0 + 2) * TP);
 #pragma unroll
         for (int i = i0; i < i1; ++i) {
-            const v4i B2 = ld_frag(p + (i + 2) * TP);
+            v4i B2;
+            if constexpr ((SESRQ_SER & 8) != 0) {       // the next row's new operand is requested a whole row ahead of its chain
+                B2 = Bn;
+                if (i + 1 < i1) Bn = ld_frag(p + (i + 3) * TP);
+            } else {
+                B2 = ld_frag(p + (i + 2) * TP);
+            }
             v4i acc = mfma(A[K][0], B0, acc0[K]);
             acc = mfma(A[K][1], B1, acc);
             acc = mfma(A[K][2], B2, acc);
@@ -186,6 +193,7 @@ __global__ __launch_bounds__(256) void mfma_trio_kernel(const TrioArgs a) {
                 q = (rok & col_in) ? q : (unsigned)L.pad_next;
             }
             d[(2 + i) * TP * 4] = q;
+            if constexpr ((SESRQ_SER & 1) != 0) __builtin_amdgcn_sched_barrier(0);
         }
     };
     // outer layer: output rows Y .. Y+NR-1 (NR = 8, or 4 in a half step) from window positions 0 .. NR+1 of layer b
@@ -218,7 +226,9 @@ __global__ __launch_bounds__(256) void mfma_trio_kernel(const TrioArgs a) {
                 B0 = B1; B1 = B2;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) s4[r][i] = acc[i];
+                if constexpr ((SESRQ_SER & 4) != 0) __builtin_amdgcn_sched_barrier(0);
             }
+            if constexpr ((SESRQ_SER & 2) != 0) __builtin_amdgcn_sched_barrier(0);
             if constexpr (LUT) {
                 const v4u rv = rcp[y4 / 4];
                 unsigned rcw[4] = {rv[0], rv[1], rv[2], rv[3]}, wq[4];
@@ -230,6 +240,7 @@ __global__ __launch_bounds__(256) void mfma_trio_kernel(const TrioArgs a) {
             } else {
                 emit_rows4<EPI_C, false, true, (U8 & 4) ? 2 : (U8 & 1)>(s4, ec, io, y4, a.l[2].zlo);
             }
+            if constexpr ((SESRQ_SER & 2) != 0) __builtin_amdgcn_sched_barrier(0);
         }
     };
     // RCW: the residual operand of frame row (window position pos) of this lane's output pixel, straight from the input window

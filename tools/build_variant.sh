@@ -1,0 +1,19 @@
+#!/bin/bash
+# Build a variant of libsesrq.so for same-box A/Bs (tools/ab.sh): tools/build_variant.sh <name> "<extra hipcc flags>" [files...]
+#   -> sesr-pytorch-quantize_amd/lib/<name>/libsesrq.so (objects of files not listed are taken from the default build)
+set -e
+ROOT=$(cd "$(dirname "$0")/.." && pwd)
+NAME=$1; EXTRA=$2; shift 2
+SRC=$ROOT/sesr-pytorch-quantize_amd/csrc; LIB=$ROOT/sesr-pytorch-quantize_amd/lib; OUT=$LIB/$NAME
+FILES=${@:-sesrq_mfma sesrq_trio}
+mkdir -p $OUT
+FLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -fno-fast-math -mllvm -amdgpu-mfma-vgpr-form -I$ROOT/include -Wall -Wno-unused-result"
+pids=()
+for f in $FILES; do /opt/rocm/bin/hipcc $FLAGS $EXTRA -c $SRC/$f.hip -o $OUT/$f.o & pids+=($!); done
+for p in "${pids[@]}"; do wait $p; done
+OBJS=""
+for f in sesrq_api sesrq_dot4 sesrq_mfma sesrq_trio sesrq_quad sesrq_verify sesrq_calib; do
+  if [ -f $SRC/$f.hip ]; then if [ -f $OUT/$f.o ]; then OBJS="$OBJS $OUT/$f.o"; else OBJS="$OBJS $LIB/$f.o"; fi; fi
+done
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $OUT/libsesrq.so $OBJS
+echo "built $OUT/libsesrq.so"
