@@ -51,20 +51,40 @@ PLAN_DEFAULT = (2, 0)
 
 
 def launch_bytes_per_px(bundle, first, count, in_f32):
-    """Algorithmic HBM bytes per input pixel of ONE launch covering layers first..first+count-1:
-    every NHWC16 int8 activation that crosses a launch boundary is written once and read once, the residual operand
-    is re-read by the launch that holds layer L-2 (unless layer 0 is in the same launch: the fused front keeps it in LDS),
-    the frame goes in as fp32 (or int8) and out as int8.  A fused trio moves 16 in + 16 out (+16 residual) -- NOT the
-    112 B/px its three layers move one by one; the fused front (layers 0-3) moves 4*Cin in + 16 out."""
+    """Algorithmic HBM bytes per input pixel of ONE launch covering layers first..first+count-1: what the launch must
+    move.  Every NHWC16 int8 activation that crosses a launch boundary is written once and read once; the frame goes in as fp32 (or
+    int8) and out as int8.  The residual operand rc (layer 0's output when zero[1] == -128, else a tensor of its own that layer 0
+    writes besides) is one more 16 B/px read for the launch that holds layer L-2 -- UNLESS that launch's own input already is that
+    tensor (first == 1, zero[1] == -128: the fused trio of the 5-conv nets takes rc out of its LDS input window, sesrq_trio.hip
+    instance 15) or layer 0 is in the same launch.  A fused trio of a 5-conv net therefore moves 16 in + 16 out = 32 B/px -- not the
+    112 B/px its three layers move one by one."""
     L = bundle.L
     cin = bundle.in_channels
     cout_last = int(bundle.layers[-1].wq.shape[0])
     last = first + count - 1
+    rc_separate = int(bundle.zero[1]) != -128
     rd = ((4 * cin) if in_f32 else cin) if first == 0 else 16
     wr = cout_last if last == L - 1 else 16
-    if first <= L - 2 <= last and first > 0:      # the fused front keeps the residual operand (its own layer-0 output) in LDS
+    holds_merge = first <= L - 2 <= last
+    if holds_merge and first > 0 and (rc_separate or first != 1):
         rd += 16
+    if first == 0 and rc_separate and not holds_merge:
+        wr += 16
     return rd + wr
+
+
+def reference_cpu_timing(workload):
+    """The reference's own CPU sim path, timed in the BUILD container (the reference cannot travel to the GPU box): a committed
+    constant written by tests/golden/make_golden.py --case time_x2_1080p for the headline workload (same net, same 1x3x1080x1920 frame,
+    dump flags off); for the other workloads the survey's SESR-x4 1080p figure, labelled as a different net."""
+    f = os.path.join(ROOT, "tests", "golden", "reference_x2_1080p.json")
+    if workload == "sesr_x2_1080p" and os.path.isfile(f):
+        r = json.load(open(f))
+        return {"value": r["frames_per_s"], "unit": "frames/s", "cores": r["cores"], "seconds_per_frame": r["seconds_median"],
+                "workload": r["workload"], "same_workload_as_timed": True,
+                "where": r["host"] + " (tests/golden/make_golden.py --case time_x2_1080p; not re-run on the GPU box)"}
+    return {"value": 0.106, "unit": "frames/s", "cores": 8, "workload": "SESR-x4 1x1x1080x1920 through the reference's own sim.py path, dump flags off",
+            "same_workload_as_timed": False, "where": "survey container (SURVEY.md 6): the reference cannot travel to the GPU box, not re-run here"}
 
 
 def layerwise_bytes_per_px(bundle, in_f32):
@@ -223,10 +243,17 @@ def main():
         parity = {"checked": f"full frame ({'x'.join(map(str, got.shape))}) of pool frame 0 vs C oracle", "max_abs_diff_int8": maxdiff,
                   "mismatches": int((diff != 0).sum()),
                   "psnr_db": "inf" if maxdiff == 0 else float(10 * np.log10(255.0 ** 2 / np.mean(diff.astype(np.float64) ** 2)))}
+        # headline workload: pool frame 0 of rank 0 is the very frame the REFERENCE itself was run on in the build container
+        # (tests/golden/reference_x2_1080p.json): the whole int8 4K frame against the reference's own output, by SHA-256
+        rf = os.path.join(ROOT, "tests", "golden", "reference_x2_1080p.json")
+        if args.workload == "sesr_x2_1080p" and os.path.isfile(rf) and B == 1 and not ekw["engine"] == _lib.ENGINE_DOT4:
+            import hashlib
+            ref = json.load(open(rf))
+            if hashlib.sha256(np.ascontiguousarray(xs).tobytes()).hexdigest() == ref["x_sha256"]:
+                parity["reference_out_q_sha256_match"] = hashlib.sha256(np.ascontiguousarray(got).tobytes()).hexdigest() == ref["out_q_sha256"]
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
-            cpu = {"reference_sim_py": {"value": 0.106, "unit": "frames/s", "cores": 8, "workload": "SESR-x4 1x1x1080x1920 through the reference's own "
-                                        "sim.py path, dump flags off", "where": "survey container (SURVEY.md 6): the reference cannot travel to the GPU box, not re-run here"},
+            cpu = {"reference_sim_py": reference_cpu_timing(args.workload),
                    "value": round(1.0 / dt, 4), "unit": "frames/s", "cores": thr, "kind": "port",
                    "sample": f"1 frame {H}x{W} of the same workload through oracle/sesrq_oracle.c (OpenMP, {thr} threads), {dt:.2f} s wall "
                              f"= {dt * thr:.0f} core-seconds of CPU work (the same run is the parity reference)"}
@@ -284,7 +311,7 @@ def main():
                          "issue": {"valu_util": prof.get("valu_util"), "mfma_util": prof.get("mfma_util"),
                                    "wait_inst_frac": prof.get("wait_inst_frac"), "lds_util": prof.get("lds_util")}}
         roofline = {"bound": "hbm", "achieved": round(ach / 1e9, 2), "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                    "frac": round(ach / HBM_PEAK, 4), "traffic": prof.get("hbm_bytes_per_launch"), "from_committed_profile": committed,
+                    "frac": round(ach / HBM_PEAK, 4), "traffic": None, "from_committed_profile": committed,
                     "kernel": f"launch{kdom}:layers{plan[kdom][0]}-{plan[kdom][0] + plan[kdom][1] - 1}:{names[plan[kdom][0]]}",
                     "kernel_ms": round(launch_ms[kdom], 5), "algorithmic_bytes_per_launch": alg[kdom],
                     "launches": [{"layers": [f, f + c - 1], "kernel": names[f], "ms": round(launch_ms[j], 5), "alg_bytes": alg[j],
@@ -295,7 +322,8 @@ def main():
                     "layerwise_frac": round(per_frame_layerwise * fps / world / HBM_PEAK, 4),
                     "note": "launches[].ms: begin/end HIP events of each kernel on the launch stream (hipExtLaunchKernelGGL inside sesrq_forward_timed: the "
                             "duration a rocprofv3 kernel trace reports); forward_device_ms: begin of the first to end of the last kernel; alg_bytes: what the "
-                            "launch must move (DESIGN 4.4; a fused trio moves 48 B/px, not its layers' 112); layerwise_frac = SURVEY "
+                            "launch must move (DESIGN 4.4; the fused trio of a 5-conv net moves 32 B/px, not its layers' 112); traffic: null -- PMC counters cannot be collected inside this run, "
+                            "the committed profile of the same kernel is under from_committed_profile; layerwise_frac = SURVEY "
                             "8(d)'s layer-by-layer bytes per frame x frames/s/GPU / peak = the north star's HBM-roofline fraction"}
 
         # ---- end to end through pinned host buffers (never `value`): H2D / compute / D2H on three streams
@@ -309,7 +337,8 @@ def main():
                   "ms_per_step": round(elapsed_med / args.steps * 1e3, 5), "higher_is_better": True,
                   "scaling": "strong" if mode == "total" else "weak",
                   "vs_baseline": None, "dtype": "i8", "data": "synthetic",
-                  "host_enqueue_us_per_step": None if res["host_enqueue_s_per_step"] is None else round(res["host_enqueue_s_per_step"] * 1e6, 1), "repeats": args.repeats, "blocks_fps": [round(args.steps * total_frames_per_step / e, 1) for e in res["elapsed"]], "spread": {"min": round(fps_all[0], 2), "median": round(fps, 2), "max": round(fps_all[-1], 2)},
+                  "host_enqueue_us_per_step": None if res["host_enqueue_s_per_step"] is None else round(res["host_enqueue_s_per_step"] * 1e6, 1),
+                  "host_enqueue_sample_steps": res["host_enqueue_sample_steps"], "repeats": args.repeats, "blocks_fps": [round(args.steps * total_frames_per_step / e, 1) for e in res["elapsed"]], "spread": {"min": round(fps_all[0], 2), "median": round(fps, 2), "max": round(fps_all[-1], 2)},
                   "config": {"workload": desc, "name": args.workload, "frames_per_step_per_gpu": B, "frames_per_step": total_frames_per_step,
                              "streams": NS, "wg_budget": args.wg_budget, "hip_graph": bool(graphs), "input_pool": f"{POOL} distinct resident frames, rotated per step",
                              "in": [B, cin, H, W], "out": list(shapes[-1]), "input_dtype": "f32", "output_dtype": "i8",

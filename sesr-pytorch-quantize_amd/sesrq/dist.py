@@ -24,6 +24,9 @@ def shard(num_frames: int, world: int, rank: int) -> range:
     return range(start, start + base + (1 if rank < extra else 0))
 
 
+HOST_SAMPLE = 16      # untimed steps behind the warm-up on which the host's enqueue time per step is measured
+
+
 def run_timed(group: "Group", step, steps: int, warmup: int, repeats: int = 1, sync=None, units_per_step: float = 1.0):
     """The measurement loop of bench.py, shared with the CPU tests so that on a multi-GPU node the RCCL backend is
     the only line that has not run before:  W untimed warm-up steps, then `repeats` blocks of EXACTLY `steps` steps,
@@ -33,7 +36,7 @@ def run_timed(group: "Group", step, steps: int, warmup: int, repeats: int = 1, s
     rate is the sum over ranks of units / the max-over-ranks time.  No data-path collective.
 
     Returns {"elapsed": [s per block], "units_per_step_total": sum over ranks, "rates": [units/s per block],
-    "host_enqueue_s_per_step": host time to enqueue one step, measured on warm-up steps 3..18 with an empty queue}."""
+    "host_enqueue_s_per_step": host time to enqueue one step, measured on HOST_SAMPLE untimed steps behind the warm-up, queue drained first}."""
     import time
     sync = sync or (lambda: None)
 
@@ -41,21 +44,16 @@ def run_timed(group: "Group", step, steps: int, warmup: int, repeats: int = 1, s
         sync()
         group.barrier()
 
-    # W warm-up steps; the host time to ENQUEUE a step is read off the steps after the first two (lazy initialisation) with
-    # the device queue drained first -- at most 16 of them, so the queue's back-pressure does not enter (the loop does not wait)
-    n0 = min(2, warmup)
-    for _ in range(n0):
+    # W warm-up steps, untimed.  Then -- still untimed, whatever W is -- HOST_SAMPLE more steps whose ENQUEUE time on the host is read
+    # off with the device queue drained first (so the queue's back-pressure does not enter: the loop does not wait); they run on a
+    # warm process (round 3 sampled warm-up steps 3..5 under --warmup 5 and read the lazy initialisation: 52.7 us vs 18-19)
+    for _ in range(warmup):
         step()
-    nt = min(16, warmup - n0)
-    host_s = None
-    if nt > 0:
-        sync()
-        tw = time.perf_counter()
-        for _ in range(nt):
-            step()
-        host_s = (time.perf_counter() - tw) / nt
-    for _ in range(warmup - n0 - nt):
+    sync()
+    tw = time.perf_counter()
+    for _ in range(HOST_SAMPLE):
         step()
+    host_s = (time.perf_counter() - tw) / HOST_SAMPLE
     elapsed = []
     for _ in range(max(1, repeats)):
         fence()
@@ -66,13 +64,13 @@ def run_timed(group: "Group", step, steps: int, warmup: int, repeats: int = 1, s
         elapsed.append(group.max_over_ranks(time.perf_counter() - t0))
     total_units = group.sum_over_ranks(units_per_step)
     return {"elapsed": elapsed, "units_per_step_total": total_units,
-            "rates": [steps * total_units / e for e in elapsed], "host_enqueue_s_per_step": host_s}
+            "rates": [steps * total_units / e for e in elapsed], "host_enqueue_s_per_step": host_s, "host_enqueue_sample_steps": HOST_SAMPLE}
 
 
 class Group:
     """Thin wrapper over torch.distributed used by bench.py; a no-op for world_size 1."""
 
-    def __init__(self, backend: Optional[str] = None, device=None):
+    def __init__(self, backend: Optional[str] = None, device=None, timeout_s: Optional[float] = None):
         self.rank, self.local_rank, self.world = env_world()
         self.dist = None
         self.device = device
@@ -81,7 +79,20 @@ class Group:
             kw = {}
             if backend == "nccl" and device is not None:
                 kw["device_id"] = device
-            dist.init_process_group(backend or "nccl", **kw)
+            if timeout_s is not None:
+                import datetime
+                kw["timeout"] = datetime.timedelta(seconds=timeout_s)
+            try:
+                dist.init_process_group(backend or "nccl", **kw)
+            except Exception as exc:      # RCCL not usable on this box (no device, IPC refused, rendezvous failed ...)
+                # A clean non-zero exit with the cause: the launcher (torchrun / the driver) sees rank failure at once.  Never a re-exec:
+                # this process may have initialised the GPU already.
+                import sys
+                print(f"sesrq.dist: init_process_group(backend={backend or 'nccl'!r}, rank {self.rank} of {self.world}, "
+                      f"MASTER_ADDR={os.environ.get('MASTER_ADDR')}:{os.environ.get('MASTER_PORT')}) failed: {type(exc).__name__}: {exc}\n"
+                      "sesrq.dist: the data path needs no collective (frames shard, bundle replicated); only the timing fence does -- "
+                      "rehearse with --dist-backend gloo, or fix the RCCL setup (HSA_ENABLE_IPC_MODE_LEGACY=0, one rank per GPU)", file=sys.stderr, flush=True)
+                raise SystemExit(3)
             self.dist = dist
 
     def barrier(self):

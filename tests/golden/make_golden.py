@@ -17,6 +17,10 @@ outputs only.  The reference's two random input tensors (data files) are re-save
 
 Usage:  python tests/golden/make_golden.py            # all cases (spawns one process per net)
         python tests/golden/make_golden.py --case sesr_x4
+        python tests/golden/make_golden.py --case time_x2_1080p   # the reference's CPU sim path TIMED on bench.py's headline workload
+                                                                   # (SESR-x2 random-init net, 1x3x1080x1920, dump flags off) + SHA-256 of its
+                                                                   # int8 / fp32 output -> reference_x2_1080p.json
+        python tests/golden/make_golden.py --case anchor          # AnchorOp (sesr_arch.py:171-205) + the eval loop's x2 add (test.py:148-155)
 """
 import argparse
 import hashlib
@@ -49,7 +53,7 @@ def sha(a: np.ndarray) -> str:
     return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
 
 
-def run_case(name: str, out_dir: str) -> None:
+def run_case(name: str, out_dir: str, time_1080p: bool = False) -> None:
     cfg = CASES[name]
     sys.dont_write_bytecode = True
     sys.path.insert(0, REF)
@@ -222,6 +226,42 @@ def run_case(name: str, out_dir: str) -> None:
                                       cal_out_sha=sha(y_cal.numpy().astype(np.float32))))),
         **{f"Wf{k}": Wf[k] for k in range(5)}, **{f"bf{k}": bf[k] for k in range(5)})
 
+    if time_1080p:
+        # bench.py's headline workload through the reference's own sim path: pool frame 0 of rank 0 (torch.Generator().manual_seed(1),
+        # torch.rand((1, 3, 1080, 1920))), the seven dump switches off (bound by value inside quan_func at import: set on the module)
+        import time
+        for flg in ("WEIGHT_W_FLG", "INPUT_W_FLG", "BIAS_W_FLG", "BIAS_QUAN_W_FLG", "OUTPUT_PE_W_FLG", "OUTPUT_PE_ADD_W_FLG", "REQUAN_FACTOR_W_FLG"):
+            assert hasattr(qf, flg), flg
+            setattr(qf, flg, False)
+        g = torch.Generator().manual_seed(1)
+        x = torch.rand((1, 3, 1080, 1920), generator=g, dtype=torch.float32)
+        sim_run(x[:, :, :64, :64].contiguous())                 # warm-up (thread pool, graph tracing paths)
+        secs = []
+        for _ in range(3):
+            t0 = time.perf_counter()
+            y = sim_run(x)
+            secs.append(time.perf_counter() - t0)
+        # graph construction (quantize_model_weight + four fx rewrites) is inside sim_run like it is inside sim.py's run; the forward alone:
+        m_secs = []
+        # dump flags are off, so input.5 is not on disk: the int8 frame is recovered from the float result, y = (q5 - z5) * f32(s5) after PixelShuffle
+        s5 = np.float32(torch.load("output_pt/input/input.5.scale.pt")); z5 = int(torch.load("output_pt/input/input.5.zero.pt"))
+        yq = np.rint(y.numpy().astype(np.float64) / np.float64(s5) + z5)
+        assert yq.min() >= -128 and yq.max() <= 127
+        yq = yq.astype(np.int8)
+        assert np.array_equal(((yq.astype(np.float32) - np.float32(z5)) * s5).astype(np.float32), y.numpy().astype(np.float32))
+        rec = dict(workload="SESR-x2 (sesr_arch_sim.sesr, the reference's seeded random init = tests/golden/sesr_x2_rand.*), 1x3x1080x1920 -> 1x3x2160x3840, "
+                            "the reference's own sim path (quantize_model_weight + 4 fx rewrites + forward, sim.py:82-114,205), dump flags off",
+                   input="torch.rand((1,3,1080,1920), generator=torch.Generator().manual_seed(1)) = bench.py pool frame 0 of rank 0",
+                   seconds=[round(t, 3) for t in secs], seconds_median=round(sorted(secs)[1], 3), frames_per_s=round(1.0 / sorted(secs)[1], 4),
+                   cores=torch.get_num_threads(), host="build container: Intel Xeon @ 2.1 GHz, 8 vCPU (nproc %d)" % (os.cpu_count() or 0),
+                   torch=torch.__version__, out_shape=list(y.shape), out_q_sha256=sha(yq), out_f_sha256=sha(y.numpy().astype(np.float32)),
+                   x_sha256=sha(x.numpy()))
+        json.dump(rec, open(os.path.join(out_dir, "reference_x2_1080p.json"), "w"), indent=1)
+        print(json.dumps(rec, indent=1), flush=True)
+        os.chdir(HERE)
+        shutil.rmtree(scratch, ignore_errors=True)
+        return
+
     # (1) full frame
     y = sim_run(x_full)
     harvest(x_full, y, "full", full=True)
@@ -317,6 +357,41 @@ def run_tables(out_dir: str) -> None:
     shutil.rmtree(scratch, ignore_errors=True)
 
 
+def run_anchor(out_dir: str) -> None:
+    """The x2 anchor of the reference: AnchorOp (models/sesr_arch.py:171-205: a frozen 1x1 conv that repeats every input channel r^2
+    times) followed by the net's own PixelShuffle(r) = nearest-neighbour upsampling of the input; the eval loop adds exactly that to
+    the x2 output (test.py:148-155: inps_x2[:, :, i::2, j::2] = inps; gfake + inps_x2).  Fixture: the reference-made upsampled input and
+    the reference-made sum for the sesr_x2_rand crop and full frame (their stored float results)."""
+    sys.dont_write_bytecode = True
+    sys.path.insert(0, REF)
+    import torch
+    from models.sesr_arch import AnchorOp
+    x_full = torch.load(os.path.join(REF, "rand_DM_Input_80x960.pt"), weights_only=True, map_location="cpu").float()
+    x_crop = x_full[:, :, 8:8 + CROP_H, 100:100 + CROP_W].contiguous()
+    op = AnchorOp(scaling_factor=2, in_channels=3)
+    ps = torch.nn.PixelShuffle(2)
+    d = {}
+    for tag, x in (("crop", x_crop), ("full", x_full)):
+        with torch.no_grad():
+            up = ps(op(x))                                     # AnchorOp + depth-to-space
+        loop = torch.zeros(x.shape[0], x.shape[1], x.shape[2] * 2, x.shape[3] * 2)      # test.py:148-153 verbatim semantics
+        loop[:, :, 0::2, 0::2] = x; loop[:, :, 0::2, 1::2] = x; loop[:, :, 1::2, 0::2] = x; loop[:, :, 1::2, 1::2] = x
+        assert torch.equal(up, loop), "AnchorOp + PixelShuffle is the eval loop's nearest upsampling"
+        g = np.load(os.path.join(out_dir, f"sesr_x2_rand.{tag}.npz"), allow_pickle=False)
+        meta = json.loads(str(g["meta"]))
+        if tag == "crop":
+            y = torch.from_numpy(g["out"])
+        else:                                                  # full frames store input5 (before PixelShuffle) only: y = (q5 - z5) * f32(s5)
+            y = ps((torch.from_numpy(g["input5"].astype(np.float32)) - float(meta["zero"][5])) * float(np.float32(meta["scale"][5])))
+            assert sha(y.numpy().astype(np.float32)) == meta["sha"]["out"]
+        s = (y + up).numpy().astype(np.float32)                # gfake + inps_x2 (test.py:154-155)
+        d[f"up_{tag}"] = up.numpy().astype(np.float32) if tag == "crop" else np.zeros(0, np.float32)
+        d[f"sum_{tag}"] = s if tag == "crop" else np.zeros(0, np.float32)
+        d[f"sha_{tag}"] = np.array(json.dumps(dict(up=sha(up.numpy().astype(np.float32)), sum=sha(s), shape=list(s.shape))))
+    np.savez_compressed(os.path.join(out_dir, "sesr_x2_rand.anchor.npz"), **d)
+    print("[anchor]", {k: (v.shape if v.ndim else str(v)) for k, v in d.items()}, flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--case", default=None)
@@ -324,6 +399,10 @@ def main():
     os.makedirs(os.path.join(HERE, "..", "..", ".scratch"), exist_ok=True)
     if args.case == "tables":
         run_tables(HERE)
+    elif args.case == "time_x2_1080p":
+        run_case("sesr_x2_rand", HERE, time_1080p=True)
+    elif args.case == "anchor":
+        run_anchor(HERE)
     elif args.case:
         run_case(args.case, HERE)
     else:
@@ -332,7 +411,7 @@ def main():
         for f in ("rand_SR_Input_80x960", "rand_DM_Input_80x960"):
             t = torch.load(os.path.join(REF, f + ".pt"), weights_only=True, map_location="cpu")
             np.save(os.path.join(HERE, f + ".npy"), t.numpy().astype(np.float32))
-        for c in list(CASES) + ["tables"]:
+        for c in list(CASES) + ["tables", "anchor", "time_x2_1080p"]:
             subprocess.run([sys.executable, os.path.abspath(__file__), "--case", c], check=True)
 
 

@@ -17,8 +17,15 @@ def test_launch_bytes_match_the_survey_accounting():
     x2 = Bundle.load(os.path.join(GOLDEN, "sesr_x2_rand.crop.npz"))
     # 159 B/px for SESR-x2 with int8 end points (+ 3 * Cin = 9 for the fp32 frame) = 168 layer by layer
     assert bench.layerwise_bytes_per_px(x2, True) == 168 and bench.layerwise_bytes_per_px(x2, False) == 159
-    # as launched: first layer, fused trio (in + residual operand + out, NOT 32 + 32 + 48), last layer
-    assert [bench.launch_bytes_per_px(x2, f, c, True) for f, c in ((0, 1), (1, 3), (4, 1))] == [28, 48, 28]
+    # as launched: first layer, fused trio (in + out: the residual operand IS its input and comes out of the LDS window; NOT its layers'
+    # 32 + 32 + 48), last layer
+    assert [bench.launch_bytes_per_px(x2, f, c, True) for f, c in ((0, 1), (1, 3), (4, 1))] == [28, 32, 28]
+    # one launch per layer (--no-fuse): layer 3 reads the residual operand as a second tensor
+    assert [bench.launch_bytes_per_px(x2, k, 1, True) for k in range(5)] == [28, 32, 32, 48, 28]
+    # zero[1] != -128: layer 0 writes the residual operand as a tensor of its own and the merging launch reads it besides its input
+    import copy
+    xz = copy.deepcopy(x2); xz.zero = list(xz.zero); xz.zero[1] = -120
+    assert [bench.launch_bytes_per_px(xz, f, c, True) for f, c in ((0, 1), (1, 3), (4, 1))] == [44, 48, 28]
     # fused front: fp32 frame in, one NHWC16 tensor out, the residual operand never leaves the CU
     assert [bench.launch_bytes_per_px(x2, f, c, True) for f, c in ((0, 4), (4, 1))] == [28, 28]
     assert 168 * 1080 * 1920 == 348364800

@@ -64,10 +64,77 @@ def test_two_rank_gloo_fence_and_sharding():
     assert all(abs(r[2] - 1.5) < 1e-12 for r in res), "MAX over ranks"
     for rank, mine, _, timed, nlog, synced in res:
         assert timed["units_per_step_total"] == 11, "sum over ranks of the frames per step"
-        assert len(timed["elapsed"]) == 2 and nlog == len(mine) * (2 + 2 * 3), "W warm-up + repeats x K steps, exactly"
+        hs = timed["host_enqueue_sample_steps"]
+        assert hs >= 16 and timed["host_enqueue_s_per_step"] >= 0.02 * 0.9
+        assert len(timed["elapsed"]) == 2 and nlog == len(mine) * (2 + hs + 2 * 3), "W warm-up + the untimed host-enqueue sample + repeats x K steps, exactly"
         # both ranks report the SLOW rank's block time (3 steps x 40 ms), not their own
         assert all(e >= 3 * 0.04 * 0.9 for e in timed["elapsed"]), timed
         assert all(abs(a - b) < 1e-9 for a, b in zip(res[0][3]["elapsed"], res[1][3]["elapsed"]))
         assert timed["rates"] == [3 * 11 / e for e in timed["elapsed"]]
         # the local drain (sync) runs on both sides of every block: before the start barrier and after the last step
-        assert synced == [len(mine) * 2, len(mine) * 5, len(mine) * 5, len(mine) * 8]
+        u = len(mine) * (2 + hs)
+        assert synced == [len(mine) * 2, u, u + len(mine) * 3, u + len(mine) * 3, u + len(mine) * 6]
+
+
+def _worker8(rank, world, port, q):
+    """config 4's split on 8 ranks: 32 frames -> 4 per rank, the whole measurement loop, rank 0 builds the one JSON line"""
+    import json
+    import time
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from sesrq.dist import Group, run_timed, shard as sh
+    g = Group(backend="gloo")
+    mine = sh(32, g.world, g.rank)
+    done = []
+
+    def step():
+        done.extend(mine)
+        time.sleep(0.002 * (1 + (rank == 5)))       # rank 5 is the straggler
+
+    res = run_timed(g, step, steps=4, warmup=1, repeats=2, sync=lambda: None, units_per_step=len(mine))
+    line = None
+    if g.rank == 0:
+        el = sorted(res["elapsed"])[len(res["elapsed"]) // 2]
+        line = json.dumps({"value": 4 * res["units_per_step_total"] / el, "n_gpus": g.world, "frames_per_step": res["units_per_step_total"],
+                           "scaling": "strong"})
+    q.put((rank, list(mine), res["elapsed"], res["units_per_step_total"], line))
+    g.close()
+
+
+def test_eight_rank_gloo_config4_split():
+    """BASELINE config 4's sharding rehearsed at its real rank count on CPU (the 8-GPU node is the driver's): shard(32, 8, r) gives every
+    rank 4 contiguous frames, the block time every rank reports is the straggler's (MAX), the job's frames per step is the SUM, and
+    only rank 0 prints.  Hardware scaling stays unmeasured until the driver's 8-GPU run."""
+    import json
+    world, port = 8, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker8, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=240) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert [r[1] for r in res] == [list(range(4 * k, 4 * k + 4)) for k in range(8)]
+    assert all(r[3] == 32 for r in res)
+    for r in res[1:]:
+        assert all(abs(a - b) < 1e-9 for a, b in zip(r[2], res[0][2])), "every rank reports the same (max-over-ranks) block time"
+        assert r[4] is None
+    assert all(e >= 4 * 0.004 * 0.9 for e in res[0][2]), "the straggler's time"
+    line = json.loads(res[0][4])
+    assert line["n_gpus"] == 8 and line["frames_per_step"] == 32 and line["value"] > 0
+
+
+def test_backend_failure_is_a_clean_exit():
+    """init_process_group("nccl") on a box without a usable device (here: no GPU at all): the rank prints what failed and exits non-zero
+    -- no hang, no traceback-only death, no re-exec."""
+    import subprocess
+    import sys
+    code = ("import os, sys; sys.path.insert(0, %r); os.environ.update(RANK='0', LOCAL_RANK='0', WORLD_SIZE='2', MASTER_ADDR='127.0.0.1', "
+            "MASTER_PORT='%d'); from sesrq.dist import Group; Group(backend='nccl', device=None, timeout_s=20)") % (
+                os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "sesr-pytorch-quantize_amd"), _free_port())
+    if torch.cuda.is_available():
+        pytest.skip("a HIP device is present: RCCL would wait for rank 1")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 3, (r.returncode, r.stderr[-400:])
+    assert "sesrq.dist: init_process_group(backend='nccl'" in r.stderr

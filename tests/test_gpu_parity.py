@@ -17,7 +17,7 @@ from sesrq import _lib
 
 pytestmark = pytest.mark.gpu
 
-STAGE_FILES = [f for f in golden_files() if not f.endswith((".params.npz", "tables.npz", ".stimtxt.npz"))]
+STAGE_FILES = [f for f in golden_files() if not f.endswith((".params.npz", "tables.npz", ".stimtxt.npz", ".anchor.npz"))]
 # kernel families behind the same ABI: dot4 (one lane per pixel), mfma (one launch per layer), trio (MFMA kernels with every
 # eligible run of three hidden 3x3 layers fused into one launch: the default), quad (fuse_hidden=2: the first layer fused in
 # front of the residual-merging trio where the net allows it, trios elsewhere)
@@ -558,6 +558,26 @@ def test_x2_anchor_add(eng):
         e.forward(torch.from_numpy(O.quantize_input(x, net.scale[0], net.zero[0])).to(_dev()))
 
 
+@pytest.mark.parametrize("eng", ENGINES, ids=[e[0] for e in ENGINES])
+def test_x2_anchor_add_against_the_reference(eng):
+    """The same option pinned on REFERENCE-MADE data (tests/golden/make_golden.py --case anchor): the reference's AnchorOp
+    (models/sesr_arch.py:171-205) + PixelShuffle of the input, added to the reference's x2 float result exactly as its eval loop
+    does (test.py:148-155), for the 24x40 crop (stored) and the 80x960 frame (SHA-256)."""
+    import json
+    from conftest import GOLDEN
+    anc = np.load(os.path.join(GOLDEN, "sesr_x2_rand.anchor.npz"), allow_pickle=False)
+    for tag in ("crop", "full"):
+        fx, meta, net, x = fixture_case(os.path.join(GOLDEN, f"sesr_x2_rand.{tag}.npz"))
+        q, y = make_engine(net, eng, anchor_add=True).forward(torch.from_numpy(x).to(_dev()))
+        want = json.loads(str(anc[f"sha_{tag}"]))
+        y = y.cpu().numpy()
+        assert list(y.shape) == want["shape"]
+        if tag == "crop":
+            _cmp("gfake + inps_x2 (reference-made)", y, anc["sum_crop"])
+            _cmp("AnchorOp + PixelShuffle (reference-made) == nearest upsampling", np.repeat(np.repeat(x, 2, axis=2), 2, axis=3), anc["up_crop"])
+        assert _sha(y.astype(np.float32)) == want["sum"], tag
+
+
 def test_randomised_shapes_against_c_oracle():
     """Stress the tile / chunk / strip boundaries of the persistent kernels: random frame sizes (around multiples of
     8 / 16 rows and 64 columns, tiny and tall), batches, all three topologies, merged / hybrid / general kernels.
@@ -727,6 +747,14 @@ def test_config2_full_frame_1080p_on_the_timed_kernels():
     per-layer kernels must give the same bytes."""
     names = ["mfma-f5-hybrid", "mfma-trio-merged", "mfma-trio-merged", "mfma-trio-merged", "mfma-h5-general"]
     e, x, q = _full_frame_case("sesr_x2_rand.crop.npz", (1, 3, 1080, 1920), 1, names)
+    # round 4: the REFERENCE ITSELF was run on this very frame in the build container (tests/golden/make_golden.py --case
+    # time_x2_1080p -> reference_x2_1080p.json): the whole int8 and fp32 4K frame against the reference's own output, by SHA-256
+    import json
+    ref = json.load(open(os.path.join(os.path.dirname(STAGE_FILES[0]), "reference_x2_1080p.json")))
+    assert _sha(x) == ref["x_sha256"]
+    q1, y1 = e.forward(torch.from_numpy(x).to(_dev()), want_q=True, want_f=True)
+    assert _sha(q1.cpu().numpy()) == ref["out_q_sha256"] and _sha(q.cpu().numpy()) == ref["out_q_sha256"]
+    assert _sha(y1.cpu().numpy()) == ref["out_f_sha256"]
     e1 = sesrq.Engine(e.bundle, _dev(), fuse_hidden=2)
     assert e1.layer_engines() == ["mfma-quad-hybrid"] * 4 + ["mfma-h5-general"]
     e2 = sesrq.Engine(e.bundle, _dev(), fuse_hidden=0)

@@ -80,7 +80,7 @@ def test_the_check_is_not_vacuous():
     assert tp < 64 and abs((float(tp) % 1.0) - 0.5) <= 2.0 ** -18 and (float(tp) % 1.0) != 0.5, (M, s, float(tp))
 
 
-PARAM_FILES = [f for f in golden_files("*.npz") if not f.endswith((".params.npz", "tables.npz", ".stimtxt.npz"))]
+PARAM_FILES = [f for f in golden_files("*.npz") if not f.endswith((".params.npz", "tables.npz", ".stimtxt.npz", ".anchor.npz"))]
 
 
 def test_host_proof_equals_numpy_restatement():

@@ -10,7 +10,7 @@ import pytest
 from conftest import golden_files, load_fixture, fixture_input, GOLDEN
 from oracle import sesrq_oracle as O
 
-STAGE_FILES = [f for f in golden_files() if not f.endswith((".params.npz", "tables.npz", ".stimtxt.npz"))]
+STAGE_FILES = [f for f in golden_files() if not f.endswith((".params.npz", "tables.npz", ".stimtxt.npz", ".anchor.npz"))]
 
 
 def _sha(a):
@@ -36,6 +36,23 @@ def test_forward_matches_reference_stage_by_stage(path):
         got = st[inv.get(name, name)]
         np.testing.assert_array_equal(np.asarray(got).astype(fx[name].dtype), fx[name], err_msg=name)
     assert list(st["y"].shape) == meta["out_shape"]
+
+
+def test_c_oracle_matches_the_reference_at_config2_size():
+    """BASELINE config 2 at full size: the reference's own sim path was run on bench.py's pool frame 0 (1x3x1080x1920, the seeded
+    random-init x2 net) in the build container (make_golden.py --case time_x2_1080p); the C oracle reproduces the SHA-256 of its int8
+    and fp32 4K frames."""
+    import json
+    import torch
+    from oracle import c_oracle as CO
+    ref = json.load(open(os.path.join(GOLDEN, "reference_x2_1080p.json")))
+    fx, meta = load_fixture(os.path.join(GOLDEN, "sesr_x2_rand.crop.npz"))
+    net = O.net_from_fixture(fx)
+    x = torch.rand((1, 3, 1080, 1920), generator=torch.Generator().manual_seed(1), dtype=torch.float32).numpy()
+    assert _sha(x) == ref["x_sha256"]
+    r = CO.forward(net, x, threads=min(os.cpu_count() or 1, 8), want_f=True)
+    assert list(r["q_out"].shape) == ref["out_shape"]
+    assert _sha(r["q_out"]) == ref["out_q_sha256"] and _sha(r["y"]) == ref["out_f_sha256"]
 
 
 def test_qconst_table():
