@@ -112,7 +112,11 @@ def main():
     ap.add_argument("--workload", default="sesr_x2_1080p", choices=sorted(WORKLOADS))
     ap.add_argument("--engine", default="auto", choices=["auto", "dot4", "mfma"])
     ap.add_argument("--no-fuse", action="store_true", help="one launch per layer (no fused hidden trio)")
-    ap.add_argument("--fuse", type=int, default=1, choices=[0, 1, 2], help="0 per layer, 1 (default) hidden trios, 2 + fused front")
+    ap.add_argument("--fuse", type=int, default=1, choices=[0, 1], help="0 per layer, 1 (default) fused hidden trios")
+    ap.add_argument("--submit", default="auto", choices=["auto", "many", "step"],
+                    help="how the steps reach the library: 'step' = one sesrq_forward per step from Python; 'many' = sesrq_forward_many, all the steps "
+                         "of a block handed over by ONE call (the C side loops over the frames and streams): the same kernels, launches and "
+                         "buffers, only the host's per-step cost changes.  auto = many for a single net without --graph, else step")
     ap.add_argument("--wg-budget", type=int, default=-1,
                     help="workgroup slots a launch may fill (sesrq_options.wg_budget; 0 = one full round of the chip).  -1 = the workload's "
                          "tuned plan (PLAN): 512 of the 1024 slots for the single-frame workloads, so that kernels of three frames stay co-resident "
@@ -191,6 +195,20 @@ def main():
             e.forward(cur, want_q=True, want_f=False, out_q=outs[slot][j], stream=stream, slot=slot, assume_ordered=True)
             cur = outs[slot][j]
         return cur
+
+    # sesrq_forward_many: frame i of the rotation = pool[i % POOL] -> outs[i % NS] on stream i % NS; one period = lcm(POOL, NS) frames
+    submit_many = (args.submit == "many" or (args.submit == "auto" and len(engines) == 1 and not args.graph)) and B > 0
+    if args.submit == "many" and (len(engines) != 1 or args.graph):
+        raise SystemExit("--submit many: single nets, without --graph (a chain interleaves two nets on each stream)")
+    sub = None
+    if submit_many:
+        import math
+        period = POOL * NS // math.gcd(POOL, NS)
+        sub = engines[0].submission([pool[i % POOL] for i in range(period)], [outs[i % NS][0] for i in range(period)], streams)
+
+    def step_many(n):
+        sub.enqueue(n, first=counter[0])
+        counter[0] += n
 
     graphs = {}
     if args.graph and B > 0:       # one graph per (stream slot, pool frame): the input pointer is part of a graph
@@ -274,7 +292,7 @@ def main():
                 pass
         torch.cuda.synchronize()
 
-    res = run_timed(grp, step, args.steps, args.warmup, repeats=args.repeats, sync=drain, units_per_step=B)
+    res = run_timed(grp, step, args.steps, args.warmup, repeats=args.repeats, sync=drain, units_per_step=B, step_many=step_many if sub else None)
     elapsed_med = statistics.median(res["elapsed"])
 
     result = None
@@ -340,7 +358,8 @@ def main():
                   "host_enqueue_us_per_step": None if res["host_enqueue_s_per_step"] is None else round(res["host_enqueue_s_per_step"] * 1e6, 1),
                   "host_enqueue_sample_steps": res["host_enqueue_sample_steps"], "repeats": args.repeats, "blocks_fps": [round(args.steps * total_frames_per_step / e, 1) for e in res["elapsed"]], "spread": {"min": round(fps_all[0], 2), "median": round(fps, 2), "max": round(fps_all[-1], 2)},
                   "config": {"workload": desc, "name": args.workload, "frames_per_step_per_gpu": B, "frames_per_step": total_frames_per_step,
-                             "streams": NS, "wg_budget": args.wg_budget, "hip_graph": bool(graphs), "input_pool": f"{POOL} distinct resident frames, rotated per step",
+                             "streams": NS, "wg_budget": args.wg_budget, "hip_graph": bool(graphs),
+                             "submit": "sesrq_forward_many: one call per timed block of K steps" if sub else "sesrq_forward per step", "input_pool": f"{POOL} distinct resident frames, rotated per step",
                              "in": [B, cin, H, W], "out": list(shapes[-1]), "input_dtype": "f32", "output_dtype": "i8",
                              "weights": [("reference random-init net, calibrated by the reference" if "rand" in f else
                                           "reference checkpoint, calibrated by this package (parity unpinned)" if "bundle" in f else

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define SESRQ_VERSION 2
+#define SESRQ_VERSION 3
 #define SESRQ_MAX_LAYERS 16
 #define SESRQ_MAX_CH 16
 
@@ -50,9 +50,8 @@ typedef struct sesrq_options {
                               * reference's eval loop, test.py:148-155: gfake + inps_x2); needs Cin*r*r == Cout and an
                               * fp32 input; the int8 output is unaffected */
     int32_t fuse_hidden;     /* 1 (default): every eligible run of three hidden 3x3 layers is ONE launch (the residual-merging trio
-                              * first); 2: additionally run the first layer inside the same launch as that trio where the net allows
-                              * it (5-conv topologies, zero[1] == -128) -- bit-identical, one launch and 32 B/px of HBM traffic
-                              * fewer, measured ~2 % slower on two streams; 0: one launch per layer */
+                              * first); 0: one launch per layer.  (Rounds 2-3 also had 2 = the first layer inside the trio's launch,
+                              * bit-identical and measured slower: retired in round 4, DESIGN.md 4.2b keeps the measurement.) */
     int32_t wg_budget;       /* workgroup slots one launch may fill; 0 (default) = one full round of the chip (occupancy x CUs).
                               * The persistent kernels cut every 64-column strip into as many vertical runs as fit the budget:
                               * a small budget leaves compute units to a concurrent stream (and makes a workgroup walk many
@@ -113,12 +112,15 @@ void sesrq_destroy(sesrq_net *net);
 /* 1 if sesrq_create proved (exhaustively, on the device) that the 3-instruction reciprocal form of
  * the input quantiser's x / scale_in is bit-identical for this net; 0 = IEEE division is used. */
 int sesrq_fast_division_proven(const sesrq_net *net);
-/* 1 (2: see below) if sesrq_create proved (all reachable sums enumerated on the host) that layer k's requant into its -128 domain,
- * clamp8(rint(fl(fl(s * M) * 2^-n - 128))) (myQL/quan_func.py:280; the output layer: :601), is bit-identical to ONE fused
- * multiply-add followed by the saturating byte convert, and the MFMA kernels therefore run that form; 0 = the two-step form
- * (other zero points, a (M, n) that fails the proof, SESRQ_DIRECT=0).  For the residual-merging layer L-2 the flag speaks of its
- * first requant (into the fixed -128 domain of ic, quan_func.py:250).  2 (output layer only): the one-fma form failed, but one fma
- * that also subtracts the 128 (a single rounding of s * M * 2^-n - 128) followed by the add of 128 is proven identical: that form runs.  No reference counterpart. */
+/* The load-time verdict on layer k's requant into its -128 domain, clamp8(rint(fl(fl(s * M) * 2^-n - 128))) (myQL/quan_func.py:280;
+ * the output layer: :601): 1 = sesrq_create proved (all reachable sums enumerated on the host) that ONE fused multiply-add followed by
+ * the saturating byte convert gives the same bits; 2 (output layer only) = that form failed, but one fma that also subtracts the 128 (a
+ * single rounding of s * M * 2^-n - 128) followed by the add of 128 is proven identical; 0 = neither, or the layer does not requantise
+ * into a -128 domain, or SESRQ_DIRECT=0.  For the residual-merging layer L-2 the flag speaks of its first requant (into the fixed -128
+ * domain of ic, quan_func.py:250).  It is a PROOF, not a launch record: the reduced form runs in the first-layer MFMA kernel, in the
+ * fused trio when all three of its layers carry the flag and every zero point its epilogues add is -128, and in the last-layer MFMA
+ * kernel (int8 output, zero[L] == -128); the per-layer hidden kernels (fuse_hidden = 0), the dot4 engine and the debug forward always
+ * run the two-step form -- the bits are the same either way.  No reference counterpart. */
 int sesrq_layer_one_fma(const sesrq_net *net, int k);
 /* The proof behind it as a host function of the requant constants alone (no device, no net): 1 = the one-fma form is
  * bit-identical to clamp8(rint(fl(fl(s * M) * 2^-n - 128))) for every accumulator value s, 2 = (output_layer != 0 only) it is
@@ -137,6 +139,21 @@ size_t sesrq_workspace_bytes(const sesrq_net *net, int N, int H, int W);
 int sesrq_forward(const sesrq_net *net, const void *in, int in_dtype, void *out_q, void *out_f,
                   int N, int H, int W, void *workspace, size_t workspace_bytes, void *stream);
 
+/* Many independent forwards enqueued by ONE call (round 4): frame k of `count` runs exactly what sesrq_forward would run for it, on
+ * streams[k % n_streams] with workspaces[k % n_streams] (frames that share a stream are ordered on it, so they may share a workspace).
+ * For callers whose frames are small enough that the HOST's per-call cost bounds the rate (540p: three launches of ~5 us each): one
+ * crossing of the language boundary per batch instead of one per frame, the launch arguments of the net built once per call.  The
+ * reference has no counterpart (it is batch-1, quan_func.py:349, 373); per frame the bytes are sesrq_forward's.  Every frames[k].in is an
+ * (N, Cin, H, W) buffer of in_dtype, out_q / out_f as in sesrq_forward (either may be NULL, not both).  Caller-owned buffers, no
+ * allocation, no synchronisation.  Returns non-zero at the first frame that fails (earlier frames stay enqueued). */
+typedef struct sesrq_frame_io {
+    const void *in;
+    void *out_q;
+    void *out_f;
+} sesrq_frame_io;
+int sesrq_forward_many(const sesrq_net *net, const sesrq_frame_io *frames, int count, int in_dtype, int N, int H, int W,
+                       void *const *workspaces, size_t workspace_bytes, void *const *streams, int n_streams);
+
 /* Debug taps mirroring the reference's dump flags (define.py:23-31).  After a forward run
  * with sesrq_forward_debug, stage tensors are written to caller buffers (device pointers, any
  * may be NULL):
@@ -145,7 +162,7 @@ int sesrq_forward(const sesrq_net *net, const void *in, int in_dtype, void *out_
  *   pe_add[k] : (N, OC_k, H, W) int32 pe_add_outputK.pt            (OUTPUT_PE_ADD_W_FLG)
  * A layer with taps runs its per-PE (general) kernel: on the MFMA engine the PE taps are written by the MFMA kernels
  * themselves; act[0] (the quantised input), the overflow counters and the pe-split last layer (OC <= 4) take their layer
- * to the dot4 kernels, which carry those taps.  The fused launches (trio, fused front) never run in a debug forward.
+ * to the dot4 kernels, which carry those taps.  The fused trio never runs in a debug forward.
  * There is no sesrq_forward_cpu (SURVEY 8b proposed one): the CPU restatement of the arithmetic is test infrastructure
  * and lives under oracle/, outside the product library. */
 typedef struct sesrq_taps {
@@ -162,7 +179,7 @@ int sesrq_forward_debug(const sesrq_net *net, const void *in, int in_dtype, void
                         const sesrq_taps *taps);
 
 /* The launch sequence of sesrq_forward for this net: launch j runs layers first[j] .. first[j]+count[j]-1
- * (count 3 = fused hidden trio, 4 = first layer + trio).  Returns the number of launches (<= n_layers); first/count may be NULL. */
+ * (count 3 = fused hidden trio).  Returns the number of launches (<= n_layers); first/count may be NULL. */
 int sesrq_launch_plan(const sesrq_net *net, int *first, int *count);
 
 /* Measurement hook: runs `iters` forwards back to back on `stream`, every kernel launched with its own begin / end

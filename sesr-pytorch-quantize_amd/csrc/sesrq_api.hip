@@ -4,7 +4,11 @@
 #include <string.h>
 
 #include <algorithm>
+#include <condition_variable>
+#include <memory>
+#include <mutex>
 #include <new>
+#include <thread>
 
 #include "sesrq_common.h"
 
@@ -285,7 +289,7 @@ int sesrq_create(const sesrq_net_desc *d, const sesrq_options *opts, sesrq_net *
     net->force_general = o.force_general ? 1 : 0;
     if (o.exact_div < 0 || o.exact_div > 2) { set_error("sesrq_create: exact_div must be 0, 1 or 2"); delete net; return 1; }
     net->div_mode = o.exact_div;
-    if (o.fuse_hidden < 0 || o.fuse_hidden > 2) { set_error("sesrq_create: fuse_hidden must be 0, 1 or 2"); delete net; return 1; }
+    if (o.fuse_hidden < 0 || o.fuse_hidden > 1) { set_error("sesrq_create: fuse_hidden must be 0 or 1"); delete net; return 1; }
     net->fuse_hidden = o.fuse_hidden;
     if (o.wg_budget < 0) { set_error("sesrq_create: wg_budget must be >= 0"); delete net; return 1; }
     net->wg_budget = o.wg_budget;
@@ -404,14 +408,6 @@ int sesrq_create(const sesrq_net_desc *d, const sesrq_options *opts, sesrq_net *
         return k >= 1 && k <= L - 2 && lp.mfma_kind == MFMA_H3 && !lp.general && lp.ic == 16 && lp.oc == 16;
     };
     for (int k = L - 4; k >= 1 && trio_ok(k) && trio_ok(k + 1) && trio_ok(k + 2); k -= 3) net->trio_len[k] = 3;
-    // fused front (sesrq_quad.hip): the first layer feeds the residual-merging trio directly (the 5-conv reference topologies), its
-    // output IS the residual operand (zero[1] == -128), and its accumulation mode is merged or hybrid with the standard bit widths
-    {
-        const LayerPlan &l0 = net->layers[0];
-        const bool hyb0 = l0.general && __builtin_popcount(l0.risky_mask) == 1 && d->pe_acc_bits == 18 && d->pe_add_bits == 20 && l0.d_afrag_others;
-        net->quad_ok = L == 5 && net->trio_len[1] == 3 && !net->rc_separate && l0.mfma_kind == MFMA_F5 && l0.oc == 16 && d->layers[0].relu &&
-                       (!l0.general || hyb0);
-    }
     {   // Residual merge (myQL/quan_func.py:256-270): q4 = clamp8(rint(fl(fl(u * M_res) * 2^-n_res + zero[L-1]))) is a function of the
         // 9-bit integer u = rc + ic + 256 alone: a 511-entry byte table replaces the second requant of the fused trio's last phase
         // (2 fma + add + cvt per value) by one LDS byte read.  Same fp32 operations, same order, as requant4<true> + round_pack.
@@ -441,7 +437,6 @@ int sesrq_create(const sesrq_net_desc *d, const sesrq_options *opts, sesrq_net *
     net->layers[0].base.fd = net->fd;
     if (!net->fd.ok) {      // no 3-instruction form for this (scale, zero), or exact_div = 1: layer 0 divides, on the dot4 kernel
         net->layers[0].engine = net->layers[0].engine_dot4;
-        net->quad_ok = false;
     }
     *out = net;
     return 0;
@@ -466,16 +461,11 @@ void sesrq_destroy(sesrq_net *net) {
 static bool trio_active(const sesrq_net *net, const sesrq_taps *taps) {
     return net->fuse_hidden && net->engine != SESRQ_ENGINE_DOT4 && !net->force_general && !taps;
 }
-// ... and so does the fused front (first layer + trio)
-static bool quad_active(const sesrq_net *net, const sesrq_taps *taps) {
-    return net->fuse_hidden >= 2 && net->quad_ok && trio_active(net, taps);
-}
 
 int sesrq_fast_division_proven(const sesrq_net *net) { return net ? net->fd_proof.ok : 0; }
 
 const char *sesrq_layer_engine(const sesrq_net *net, int k) {
     if (!net || k < 0 || k >= net->L) return "";
-    if (quad_active(net, nullptr) && k < 4) return net->layers[0].general ? "mfma-quad-hybrid" : "mfma-quad-merged";
     for (int j = std::max(1, k - 2); j <= k; ++j)
         if (trio_active(net, nullptr) && net->trio_len[j] == 3 && k < j + 3) return "mfma-trio-merged";
     return net->layers[k].engine.c_str();
@@ -490,7 +480,7 @@ int sesrq_launch_plan(const sesrq_net *net, int *first, int *count) {
     if (!net) return 0;
     int n = 0;
     for (int k = 0; k < net->L;) {
-        const int c = (k == 0 && quad_active(net, nullptr)) ? 4 : ((trio_active(net, nullptr) && net->trio_len[k] == 3) ? 3 : 1);
+        const int c = (trio_active(net, nullptr) && net->trio_len[k] == 3) ? 3 : 1;
         if (first) first[n] = k;
         if (count) count[n] = c;
         ++n;
@@ -538,44 +528,6 @@ static int forward_impl(const sesrq_net *net, const void *in, int in_dtype, void
     struct ClearKernelEvents { ~ClearKernelEvents() { tl_kernel_events = KernelEvents{}; } } clear_on_any_exit;
     for (int k = 0; k < L; ++launch) {
         const LayerPlan &lp = net->layers[k];
-        if (k == 0 && quad_active(net, taps)) {
-            // ---- fused front: layers 0..3 in one launch (sesrq_quad.hip)
-            QuadArgs q;
-            memset(&q, 0, sizeof(q));
-            TrioArgs &t = q.t;
-            void *dst = bufA;
-            t.out = dst;
-            t.N = N; t.H = H; t.W = W;
-            t.wg_budget = net->wg_budget;
-            t.pad_in = net->layers[1].base.pad_word;
-            t.Mres = lp.base.Mres; t.shres = lp.base.shres; t.z_merge = lp.base.z_merge;
-            for (int j = 0; j < 3; ++j) {
-                const LayerPlan &lj = net->layers[1 + j];
-                t.l[j].afrag = lj.d_afrag_merged;
-                t.l[j].Mf = lj.base.Mf; t.l[j].sh = lj.base.sh; t.l[j].z_next = lj.base.z_next; t.l[j].Md = lj.base.Md; t.l[j].Cd = lj.base.Cd; t.l[j].direct = lj.base.direct;
-                t.l[j].zlo = lj.base.relu ? fmaxf(lj.base.z_next, -128.f) : -128.f;
-                t.l[j].pad_next = net->layers[2 + j].base.pad_word;
-            }
-            q.frame = in;
-            q.afrag0 = lp.general ? lp.d_afrag_others : lp.d_afrag_merged;
-            q.afrag0r = lp.general ? lp.d_afrag_general : nullptr;
-            q.risky_pe = lp.general ? __builtin_ctz(lp.risky_mask) : 0;
-            q.ic = lp.ic;
-            q.Mf0 = lp.base.Mf; q.sh0 = lp.base.sh; q.z1 = lp.base.z_next;
-            q.zlo0 = fmaxf(lp.base.z_next, -128.f);
-            q.pad_raw = lp.base.pad_word;
-            q.s_in = lp.base.s_in; q.z_in = lp.base.z_in;
-            q.s_prev = net->i8_in_scale; q.z_prev = (float)net->i8_in_zero;
-            q.fd = net->fd;
-            const int src = in_dtype == SESRQ_F32 ? SRC_F32 : (net->i8_in_scale > 0.f ? SRC_I8D : SRC_I8);
-            if (launch >= NL) { set_error("sesrq_forward: more launches than sesrq_launch_plan reports"); return 1; }
-            if (ev) tl_kernel_events = KernelEvents{ev[2 * launch], ev[2 * launch + 1]};     // begin / end events of the next kernel
-            if (launch_quad(q, lp.general, src, st)) return 1;
-            tl_kernel_events = KernelEvents{};
-            cur = dst;
-            k += 4;
-            continue;
-        }
         if (trio_active(net, taps) && net->trio_len[k] == 3) {
             // ---- fused hidden trio: layers k, k+1, k+2 in one launch (sesrq_trio.hip)
             TrioArgs t;
@@ -610,9 +562,8 @@ static int forward_impl(const sesrq_net *net, const void *in, int in_dtype, void
         // input tap and the pe-split last layer (OC <= 4) stay with the dot4 kernels
         const bool mfma_ok = net->engine != SESRQ_ENGINE_DOT4 && lp.mfma_kind != MFMA_NONE && (k > 0 || net->fd.ok);
         const bool tap_mfma = dbg && !taps->overflow && !q0tap && mfma_ok && !lp.d_afrag_pesplit;
-        LayerPlan eff = lp;
-        eff.general = lp.general || net->force_general || dbg;
-        a.wpk = eff.general ? lp.d_wpk_general : lp.d_wpk_merged;
+        const bool general = lp.general || net->force_general || dbg;      // per-PE sums + clamps
+        a.wpk = general ? lp.d_wpk_general : lp.d_wpk_merged;
         a.N = N; a.H = H; a.W = W;
         a.wg_budget = net->wg_budget;
         a.in = cur;
@@ -639,7 +590,7 @@ static int forward_impl(const sesrq_net *net, const void *in, int in_dtype, void
         if (ev) tl_kernel_events = KernelEvents{ev[2 * launch], ev[2 * launch + 1]};     // begin / end events of the next kernel
         const bool use_mfma = mfma_ok && (!dbg || tap_mfma) && !q0tap;
         if (use_mfma) {
-            a.afrag = eff.general ? lp.d_afrag_general : lp.d_afrag_merged;
+            a.afrag = general ? lp.d_afrag_general : lp.d_afrag_merged;
             // exactly one PE can saturate (and nothing forces the full per-PE path): merged chain + that PE's chain
             const bool one_pe = lp.general && !net->force_general && !dbg && lp.d_afrag_others && net->acc_bits == 18 && net->add_bits == 20;
             if (one_pe) {
@@ -651,8 +602,8 @@ static int forward_impl(const sesrq_net *net, const void *in, int in_dtype, void
                     if (lp.risky_oc && (lp.risky_oc & ~(0xf << (4 * i))) == 0) a.risky_reg = i;
             }
             if (lp.d_afrag_pesplit) a.afrag = lp.d_afrag_pesplit;
-            if (launch_mfma(lp, a, src, epi, eff.general, st, one_pe, tap_mfma)) return 1;
-        } else if (launch_dot4(eff, a, src, epi, st)) return 1;
+            if (launch_mfma(lp, a, src, epi, general, st, one_pe, tap_mfma)) return 1;
+        } else if (launch_dot4(lp, general, a, src, epi, st)) return 1;
         tl_kernel_events = KernelEvents{};
         cur = dst;
         ++k;
@@ -668,6 +619,123 @@ int sesrq_forward_debug(const sesrq_net *net, const void *in, int in_dtype, void
 int sesrq_forward(const sesrq_net *net, const void *in, int in_dtype, void *out_q, void *out_f, int N, int H, int W,
                   void *workspace, size_t workspace_bytes, void *stream) {
     return forward_impl(net, in, in_dtype, out_q, out_f, N, H, W, workspace, workspace_bytes, stream, nullptr, nullptr);
+}
+
+}  // extern "C"  (the submission pool below is C++)
+
+namespace {
+// Submission pool of sesrq_forward_many: one persistent host thread per extra stream.  A HIP kernel launch costs the calling thread
+// ~3.5 us (round 4, 540p workloads: 10.8-11.2 us per frame of three launches from one thread, where the device needs ~11 us per frame
+// when fed): the launches of DIFFERENT streams are independent, so each stream's frames are enqueued by a thread of its own, in order.
+struct SubmitJob {
+    const sesrq_net *net; const sesrq_frame_io *frames; int count, first, stride, in_dtype, N, H, W;
+    void *ws; size_t ws_bytes; void *stream;
+    int rc = 0, bad = -1; std::string err;
+};
+static int run_job(SubmitJob &j) {
+    for (int k = j.first; k < j.count; k += j.stride)
+        if (forward_impl(j.net, j.frames[k].in, j.in_dtype, j.frames[k].out_q, j.frames[k].out_f, j.N, j.H, j.W, j.ws, j.ws_bytes, j.stream,
+                         nullptr, nullptr)) {
+            j.rc = 1; j.bad = k; j.err = sesrq_last_error();
+            return 1;
+        }
+    return 0;
+}
+class SubmitPool {
+    struct Worker {
+        std::thread th;
+        std::mutex mu;
+        std::condition_variable cv;
+        SubmitJob *job = nullptr;
+        bool done = true, quit = false;
+    };
+    std::vector<std::unique_ptr<Worker>> workers;
+    std::mutex call_mu;      // one sesrq_forward_many at a time uses the pool (a second concurrent caller enqueues on its own thread)
+    static void loop(Worker *w) {
+        int dev = -1;
+        for (;;) {
+            std::unique_lock<std::mutex> lk(w->mu);
+            w->cv.wait(lk, [&] { return w->job || w->quit; });
+            if (w->quit) return;
+            SubmitJob *j = w->job;
+            lk.unlock();
+            if (dev != j->net->device) { dev = j->net->device; (void)hipSetDevice(dev); }      // a fresh thread starts on device 0
+            run_job(*j);
+            lk.lock();
+            w->job = nullptr; w->done = true;
+            lk.unlock();
+            w->cv.notify_all();
+        }
+    }
+public:
+    ~SubmitPool() {
+        for (auto &w : workers) {
+            { std::lock_guard<std::mutex> lk(w->mu); w->quit = true; }
+            w->cv.notify_all();
+            if (w->th.joinable()) w->th.join();
+        }
+    }
+    // jobs[0] runs on the caller's thread, jobs[1..] on the workers; false = the pool is busy (caller falls back to one thread)
+    bool run(std::vector<SubmitJob> &jobs) {
+        std::unique_lock<std::mutex> call(call_mu, std::try_to_lock);
+        if (!call.owns_lock()) return false;
+        while (workers.size() + 1 < jobs.size()) {
+            workers.emplace_back(new Worker());
+            Worker *w = workers.back().get();
+            w->th = std::thread(loop, w);
+        }
+        for (size_t i = 1; i < jobs.size(); ++i) {
+            Worker *w = workers[i - 1].get();
+            { std::lock_guard<std::mutex> lk(w->mu); w->job = &jobs[i]; w->done = false; }
+            w->cv.notify_all();
+        }
+        run_job(jobs[0]);
+        for (size_t i = 1; i < jobs.size(); ++i) {
+            Worker *w = workers[i - 1].get();
+            std::unique_lock<std::mutex> lk(w->mu);
+            w->cv.wait(lk, [&] { return w->done; });
+        }
+        return true;
+    }
+};
+static SubmitPool &submit_pool() { static SubmitPool p; return p; }
+}  // namespace
+
+extern "C" {
+
+int sesrq_forward_many(const sesrq_net *net, const sesrq_frame_io *frames, int count, int in_dtype, int N, int H, int W,
+                       void *const *workspaces, size_t workspace_bytes, void *const *streams, int n_streams) {
+    if (!net || !frames || !workspaces || !streams) { set_error("sesrq_forward_many: null argument"); return 1; }
+    if (count < 0 || n_streams < 1 || n_streams > 64) { set_error("sesrq_forward_many: count must be >= 0 and n_streams in 1..64"); return 1; }
+    for (int s = 0; s < std::min(n_streams, count); ++s)
+        if (!workspaces[s]) { set_error("sesrq_forward_many: null workspace"); return 1; }
+    // SESRQ_SUBMIT_THREADS=0: everything from the calling thread (frame order k = 0, 1, 2, ...); default: one thread per stream when a
+    // stream gets at least two frames (fewer: waking a thread costs more than the launches it takes over)
+    static const int threads_knob = env_knob("SESRQ_SUBMIT_THREADS", 1, 0, 1);
+    std::vector<SubmitJob> jobs;
+    const bool pooled = threads_knob && n_streams > 1 && count >= 2 * n_streams;
+    const int nj = pooled ? n_streams : 1;
+    if (pooled) {
+        for (int s = 0; s < n_streams; ++s)
+            jobs.push_back(SubmitJob{net, frames, count, s, n_streams, in_dtype, N, H, W, workspaces[s], workspace_bytes, streams[s]});
+        if (!submit_pool().run(jobs)) jobs.clear();
+    }
+    if (jobs.empty()) {      // one thread: frames in order, frame k on stream k % n_streams
+        for (int k = 0; k < count; ++k) {
+            const int s = k % n_streams;
+            if (forward_impl(net, frames[k].in, in_dtype, frames[k].out_q, frames[k].out_f, N, H, W, workspaces[s], workspace_bytes, streams[s],
+                             nullptr, nullptr)) {
+                set_error("sesrq_forward_many: frame " + std::to_string(k) + ": " + sesrq_last_error());
+                return 1;
+            }
+        }
+        return 0;
+    }
+    int bad = -1;
+    for (int j = 0; j < nj; ++j)
+        if (jobs[j].rc && (bad < 0 || jobs[j].bad < jobs[bad].bad)) bad = j;
+    if (bad >= 0) { set_error("sesrq_forward_many: frame " + std::to_string(jobs[bad].bad) + ": " + jobs[bad].err); return 1; }
+    return 0;
 }
 
 int sesrq_forward_timed(const sesrq_net *net, const void *in, int in_dtype, void *out_q, void *out_f, int N, int H, int W,

@@ -43,7 +43,7 @@ inline int env_knob(const char *name, int dflt, int lo, int hi) {
 
 enum Epi { EPI_MID = 0, EPI_PRERES = 1, EPI_LAST = 2 };
 
-// First layer (MFMA_F5 images; kernels: mfma_f5_kernel, mfma_quad_kernel): a pixel is one dword (byte c = channel c).  K-chunk 0 = the
+// First layer (MFMA_F5 images; kernel: mfma_f5_kernel): a pixel is one dword (byte c = channel c).  K-chunk 0 = the
 // 4x4 block of taps (lane group g = kernel row g, dwords = kx 0..3); K-chunk 1 = the 9 taps of kernel row 4 and column 4, covered
 // by four translates f5_tr(g) of ONE 4-pixel pattern {(0,0),(1,0),(1,1),(1,2)}: the two lane groups of a 32-lane half are an odd
 // number of rows apart (3|0 and 3|2), which the column-major LDS image of mfma_f5_kernel needs for conflict-free dword reads.
@@ -182,19 +182,6 @@ struct TrioArgs {
     TrioLayer l[3];
 };
 
-// fused front (sesrq_quad.hip): the first 5x5 layer + the hidden trio in one launch
-struct QuadArgs {
-    TrioArgs t;              // t.in / t.rc_in unused: the trio's input and the residual operand come from the first-layer phase
-    const void *frame;       // (N, ic, H, W) fp32 | int8
-    const int4 *afrag0;      // first layer: merged A-fragment image (hybrid: the image without the risky PE)
-    const int4 *afrag0r;     // hybrid: the general image (the risky PE's chain), else NULL
-    int risky_pe, ic;
-    float Mf0, sh0, z1, zlo0;
-    int pad_raw;             // zc of the frame's domain replicated into 4 bytes
-    float s_in, z_in, s_prev, z_prev;
-    FastDiv fd;
-};
-
 struct LayerPlan {
     int k, ic, oc, ocp;
     bool general;            // per-PE accumulators + 18/20-bit clamps needed
@@ -218,11 +205,10 @@ struct LayerPlan {
 void set_error(const std::string &msg);
 
 // dot4 engine
-int launch_dot4(const LayerPlan &lp, const ConvArgs &a, int src, int epi, hipStream_t st);
+int launch_dot4(const LayerPlan &lp, bool general, const ConvArgs &a, int src, int epi, hipStream_t st);      // general: per-PE sums + clamps
 // mfma engine
 int launch_mfma(const LayerPlan &lp, const ConvArgs &a, int src, int epi, bool general, hipStream_t st, bool one_risky_pe = false, bool tap = false);
 int launch_trio(const TrioArgs &a, int epi_c, hipStream_t st);
-int launch_quad(const QuadArgs &a, bool hybrid, int src, hipStream_t st);
 int launch_unpack_nhwc16(const void *nhwc, signed char *nchw, int N, int C, int H, int W, hipStream_t st);
 
 }  // namespace sesrq
@@ -246,7 +232,6 @@ struct sesrq_net {
     int i8_in_zero = 0;
     int *d_merge_lut = nullptr;         // device: 512-byte table of the residual merge (see TrioArgs::merge_lut)
     std::vector<int> trio_len;          // trio_len[k] == 3: layers k..k+2 are eligible for the fused hidden trio
-    bool quad_ok = false;               // layers 0..3 eligible for the fused front (first layer + residual-merging trio)
     int device = 0;
     bool rc_separate = false;   // zero[1] != -128 -> layer 0 writes its own rc tensor
     sesrq::FastDiv fd = {0, 0.f, 0.f, 0.f, 0.f};

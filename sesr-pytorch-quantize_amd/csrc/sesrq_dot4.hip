@@ -258,10 +258,10 @@ static int dispatch(const LayerPlan &lp, const ConvArgs &a, int src, int epi, hi
     return 1;
 }
 
-int launch_dot4(const LayerPlan &lp, const ConvArgs &a, int src, int epi, hipStream_t st) {
+int launch_dot4(const LayerPlan &lp, bool general, const ConvArgs &a, int src, int epi, hipStream_t st) {
     int rc;
-    if (lp.k == 3) rc = lp.general ? dispatch<3, true>(lp, a, src, epi, st) : dispatch<3, false>(lp, a, src, epi, st);
-    else if (lp.k == 5) rc = lp.general ? dispatch<5, true>(lp, a, src, epi, st) : dispatch<5, false>(lp, a, src, epi, st);
+    if (lp.k == 3) rc = general ? dispatch<3, true>(lp, a, src, epi, st) : dispatch<3, false>(lp, a, src, epi, st);
+    else if (lp.k == 5) rc = general ? dispatch<5, true>(lp, a, src, epi, st) : dispatch<5, false>(lp, a, src, epi, st);
     else { set_error("dot4: kernel size must be 3 or 5"); return 1; }
     if (rc) return rc;
     hipError_t e = hipGetLastError();

@@ -38,14 +38,8 @@
 
 namespace sesrq {
 
-#ifndef SESRQ_STAGE_INTERIOR
-#define SESRQ_STAGE_INTERIOR 1     /* A/B knob: 0 = every staged pixel goes through the pad select */
-#endif
 constexpr int MTW = 64;   // tile width : 4 waves x 16 pixels
-#ifndef SESRQ_MTH
-#define SESRQ_MTH 8
-#endif
-constexpr int MTH = SESRQ_MTH;    // tile height: rows walked by every wave (multiple of 4); 8 beats 12 and 16 on 1080p (latency hiding vs halo)
+constexpr int MTH = 8;    // tile height: rows walked by every wave (multiple of 4); 8 beats 12 and 16 on 1080p (latency hiding vs halo)
 
 // last layer: requantise into the output domain + PixelShuffle(r) store (int8 and/or fp32).
 // A lane owns output slots o = 4g..4g+3 of pixel (gy, gx); everything that depends only on the lane
@@ -100,26 +94,17 @@ struct LastStore {
         if constexpr (FASTD >= 10) {
             static_assert(BIASED && FAST != 0, "one-fma requant: biased sums, int8 output");
             // FASTD 2x (ConvArgs::direct == 2): the fma also subtracts the 128 (one rounding of s*M*2^-n - 128), one add brings it back
-            v2f w01, w23;
-            if constexpr (SESRQ_UNPACK) {
-                const float cv = in_vgpr(FASTD >= 20 ? a.Cs : a.Cd), mv = in_vgpr(a.Md);
-                float t[4] = {0.f, 0.f, 0.f, 0.f};
+            // plain v_fma_f32 / v_add_f32 with every operand in a VGPR (see fma4_biased, sesrq_mfma_common.h)
+            const float cv = in_vgpr(FASTD >= 20 ? a.Cs : a.Cd), mv = in_vgpr(a.Md);
+            float t[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int i = 0; i < NV; ++i) t[i] = __builtin_fmaf(__builtin_bit_cast(float, s[i]), mv, cv);
-                if constexpr (FASTD >= 20) {
-                    const float kv = in_vgpr(128.f);
+            for (int i = 0; i < NV; ++i) t[i] = __builtin_fmaf(__builtin_bit_cast(float, s[i]), mv, cv);
+            if constexpr (FASTD >= 20) {
+                const float kv = in_vgpr(128.f);
 #pragma unroll
-                    for (int i = 0; i < NV; ++i) t[i] = __fadd_rn(t[i], kv);
-                }
-                w01 = (v2f){t[0], t[1]}; w23 = (v2f){t[2], t[3]};
-            } else {
-            const float cv = in_vgpr(FASTD >= 20 ? a.Cs : a.Cd);
-            const v2f M2 = {a.Md, a.Md}, c2 = {cv, cv};
-            const v2f y01 = {__builtin_bit_cast(float, s[0]), __builtin_bit_cast(float, s[1])};
-            const v2f y23 = {__builtin_bit_cast(float, s[2]), __builtin_bit_cast(float, s[NV == 4 ? 3 : 2])};
-            w01 = __builtin_elementwise_fma(y01, M2, c2); w23 = __builtin_elementwise_fma(y23, M2, c2);
-            if constexpr (FASTD >= 20) { const float kv = in_vgpr(128.f); const v2f k = {kv, kv}; w01 = w01 + k; w23 = w23 + k; }      // a VGPR operand: 1.4 ns, a literal 2.1
+                for (int i = 0; i < NV; ++i) t[i] = __fadd_rn(t[i], kv);
             }
+            const v2f w01 = {t[0], t[1]}, w23 = {t[2], t[3]};
             unsigned w = __builtin_amdgcn_cvt_pk_u8_f32(w01[0], 0, 0u);
             w = __builtin_amdgcn_cvt_pk_u8_f32(w01[1], 1, w);
             w = __builtin_amdgcn_cvt_pk_u8_f32(w23[0], 2, w);
@@ -225,7 +210,7 @@ struct StageNHWC16 {
     __amdgpu_buffer_rsrc_t rs;
     int row_bytes;
     __device__ __forceinline__ void set_interior(const ConvArgs &a, int x0, int y0) {
-        interior = SESRQ_STAGE_INTERIOR && (x0 - R >= 0) && (x0 - R + SW <= a.W) && (y0 - R >= 0) && (y0 - R + SH <= a.H);
+        interior = (x0 - R >= 0) && (x0 - R + SW <= a.W) && (y0 - R >= 0) && (y0 - R + SH <= a.H);
     }
     // Addresses are lane constants + ONE scalar per tile (soffset = y0 * W * 16): the loop issues its
     // loads without touching a VGPR, so nothing forces a wait on the previous tile's stores.  Rows
@@ -442,15 +427,11 @@ __global__ __launch_bounds__(256) void mfma_h3_kernel(const ConvArgs a) {
 
 // ------------------------------------------------------------------ 5x5, 16 input channels
 // FAST (EPI_LAST only): 2 / 4 = PixelShuffle factor, int8 output only (LastStore::store); 0 = every output kind
-// Waves per SIMD the register allocation is held to (A/B knob).  Round 3, same-box A/B at 1080p: 5 waves (96 VGPRs, a handful of
-// spills outside the row loop, a fifth workgroup per CU) ran the last layer 5 % SLOWER than 4 (29.3 vs 27.7 us) and the fused trio
-// 13 % slower (47.1 vs 41.6 us): the SIMDs' instruction issue is already ~80-90 % occupied by four waves.
-#ifndef SESRQ_H5_WAVES
-#define SESRQ_H5_WAVES 4
-#endif
+// 4 waves per SIMD: round 3, same-box A/B at 1080p: 5 waves (96 VGPRs, a handful of spills outside the row loop, a fifth workgroup per
+// CU) ran the last layer 5 % SLOWER than 4 (29.3 vs 27.7 us) and the fused trio 13 % slower (47.1 vs 41.6 us).
 // NV (EPI_LAST only): real accumulator rows per lane group, 3 for up to 12 output channels (last_slot_oc, sesrq_common.h)
 template <int MODE, int EPI, int FAST = 0, int NV = 4>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SESRQ_H5_WAVES))) void mfma_h5_kernel(const ConvArgs a) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void mfma_h5_kernel(const ConvArgs a) {
     constexpr bool GENERAL = mode_general(MODE);
     constexpr int SW = MTW + 8;          // 2 + 64 + 2 halo, + over-read of the kx = 4..7 group
     constexpr int SH = MTH + 4;
@@ -573,16 +554,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SESRQ_H5_WA
 #pragma unroll
                     for (int p = 0; p < 4; ++p) {
                         const int o = y4 + (r + p * CP);
-#ifdef SESRQ_H5_FAKE64      /* throwaway timing experiment: 8-byte-aligned ds_read_b64 at (wrong) rounded-down addresses */
-                        typedef int v2ia __attribute__((ext_vector_type(2)));
-                        typedef const v2ia __attribute__((address_space(3))) *lds_apair_t;
-                        const int o8 = (o & ~1) * 4;
-                        const v2ia a0 = *(lds_apair_t)(size_t)((pb[0][0] & ~7u) + o8), a1 = *(lds_apair_t)(size_t)((pb[0][1] & ~7u) + o8);
-                        const v2ia c0 = *(lds_apair_t)(size_t)((pb[1][0] & ~7u) + o8), c1 = *(lds_apair_t)(size_t)((pb[1][1] & ~7u) + o8);
-#else
                         const v2iu a0 = *(lds_pair_t)(size_t)(pb[0][0] + 4 * o), a1 = *(lds_pair_t)(size_t)(pb[0][1] + 4 * o);
                         const v2iu c0 = *(lds_pair_t)(size_t)(pb[1][0] + 4 * o), c1 = *(lds_pair_t)(size_t)(pb[1][1] + 4 * o);
-#endif
                         const v4i b0 = {a0[0], a0[1], a1[0], a1[1]};
                         const v4i b1 = {c0[0], c0[1], c1[0], c1[1]};
                         acc[p] = mfma(A[p], b0, zero);
@@ -696,15 +669,6 @@ __global__ __launch_bounds__(256) void mfma_h5p_kernel(const ConvArgs a) {
 // distinct even banks and the two lane groups of a 32-lane half an odd number of rows apart, i.e. on the odd banks.
 // NCH: input channels as a compile-time count (1 and 3 are the reference's nets), or 4 = "a.ic of them, tested per channel":
 // the wave-uniform test put every channel's load and quantise code into a block of its own.
-#ifndef SESRQ_F5_ZPAD
-#define SESRQ_F5_ZPAD 1       /* A/B knob: 0 = one descriptor over the image, row test + pad-word select per staged pixel */
-#endif
-#ifndef SESRQ_F5_VCONST
-#define SESRQ_F5_VCONST 1     /* A/B knob: 0 = the input quantiser's constants as scalar operands */
-#endif
-#ifndef SESRQ_F5_CARRY
-#define SESRQ_F5_CARRY 1      /* A/B knob: 0 = every tile of a run stages (loads + quantises) its whole window, halo rows included */
-#endif
 template <int SRC, int SH, int SWP, int PITCH, int NCH>
 struct StageFrame {
     __device__ __forceinline__ static bool has_channel(const ConvArgs &a, int c) { return NCH < 4 ? c < NCH : c < a.ic; }
@@ -714,7 +678,7 @@ struct StageFrame {
     // above (negative total offset) or below (past the plane: the range check sees voffset + soffset, tools/oob_probe.hip) -- then
     // loads 0.0f, and q0(0.0) = clamp8(z0) IS the pad value of the first layer (the zero point stands for 0.0): no row test, no
     // select of a pad word.  With one descriptor over the whole image a row below plane c would read plane c + 1.
-    static constexpr bool ZPAD = SESRQ_F5_ZPAD && SRC == SRC_F32;
+    static constexpr bool ZPAD = SRC == SRC_F32;
     unsigned raw[NIT][4];
     bool ok[NIT];
     int voff[NIT], ty[NIT];
@@ -733,7 +697,7 @@ struct StageFrame {
             for (int c = 0; c < (NCH < 4 ? NCH : 4); ++c)
                 rsp[c] = __builtin_amdgcn_make_buffer_rsrc((char *)const_cast<void *>(a.in) + (size_t)n_img * img + (size_t)(c < a.ic ? c : 0) * plane_bytes, 0, plane_bytes, 0x00020000);
         }
-        if constexpr (SRC != SRC_I8 && SESRQ_F5_VCONST) {
+        if constexpr (SRC != SRC_I8) {
             qc.xlo = pin(a.fd.xlo); qc.xhi = pin(a.fd.xhi); qc.r = pin(a.fd.r); qc.ns = pin(-a.s_in); qc.r2 = pin(a.fd.r2); qc.z = pin(a.z_in);
             qc.magic = pin(MAGIC);
         }
@@ -750,7 +714,7 @@ struct StageFrame {
     // Tiles of a run are stacked: the top CARRY = SH - TH rows of the next tile's staged window are the bottom CARRY rows of this
     // one's.  They are copied inside the LDS (store_next) instead of being loaded and quantised again: a following tile stages
     // only its TH new rows (element i -> row CARRY + i / SWP, same column), 864 pixels instead of 1152.
-    static constexpr int CARRY = SESRQ_F5_CARRY ? 4 : 0;
+    static constexpr int CARRY = 4;
     static constexpr int NITN = ((SH - CARRY) * SWP + 255) / 256;
     template <bool FIRST>
     __device__ __forceinline__ void load_t(const ConvArgs &a, int y0) {
@@ -792,11 +756,9 @@ struct StageFrame {
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 if constexpr (SRC == SRC_F32)
-                    b[c] = SESRQ_F5_VCONST ? quantize_in_bits(__builtin_bit_cast(float, raw[it][c]), qc)
-                                           : quantize_in_bits(__builtin_bit_cast(float, raw[it][c]), a.s_in, a.z_in, a.fd);
+                    b[c] = quantize_in_bits(__builtin_bit_cast(float, raw[it][c]), qc);
                 else if constexpr (SRC == SRC_I8D)      // upstream net's int8 output: its float value, then this net's input quantiser
-                    b[c] = SESRQ_F5_VCONST ? quantize_in_bits(__fmul_rn((float)(int)raw[it][c] - a.z_prev, a.s_prev), qc)
-                                           : quantize_in_bits(__fmul_rn((float)(int)raw[it][c] - a.z_prev, a.s_prev), a.s_in, a.z_in, a.fd);
+                    b[c] = quantize_in_bits(__fmul_rn((float)(int)raw[it][c] - a.z_prev, a.s_prev), qc);
                 else
                     b[c] = raw[it][c];
                 if (!has_channel(a, c)) b[c] = 0;
@@ -815,30 +777,16 @@ struct StageFrame {
     // a following tile: rows SH-CARRY .. SH-1 of the tile under computation (cur, read-only by now) become rows 0 .. CARRY-1 of nxt
     // (a column's rows are adjacent dwords: two 8-byte moves per column), then the new rows
     __device__ __forceinline__ void store_next(int4 *nxt, const int4 *cur, const ConvArgs &a, int tid) const {
-        if constexpr (CARRY == 0) { store_t<true>(nxt, a, tid); return; }
         static_assert(PITCH % 2 == 0 && (SH - 4) % 2 == 0 && 2 * SWP <= 256, "8-byte carry moves");
-#ifndef SESRQ_F5_CARRY_MODE
-#define SESRQ_F5_CARRY_MODE 1
-#endif
-        const int ct = SESRQ_F5_CARRY_MODE == 2 ? 255 - tid : tid;      // mode 2: the waves with one quantiser iteration less do the copy
-        const int cc = (ct >> 1) * PITCH + 2 * (ct & 1);      // the read is issued first, the quantiser's VALU work covers its latency
+        const int cc = (tid >> 1) * PITCH + 2 * (tid & 1);      // the read is issued first, the quantiser's VALU work covers its latency
         int2 v = {0, 0};
-        if (SESRQ_F5_CARRY_MODE != 3 && ct < 2 * SWP) v = *reinterpret_cast<const int2 *>(reinterpret_cast<const int *>(cur) + cc + (SH - 4));
+        if (tid < 2 * SWP) v = *reinterpret_cast<const int2 *>(reinterpret_cast<const int *>(cur) + cc + (SH - 4));
         store_t<false>(nxt, a, tid);
-        if (SESRQ_F5_CARRY_MODE != 3 && ct < 2 * SWP) *reinterpret_cast<int2 *>(reinterpret_cast<int *>(nxt) + cc) = v;
+        if (tid < 2 * SWP) *reinterpret_cast<int2 *>(reinterpret_cast<int *>(nxt) + cc) = v;
     }
 };
 
-#ifndef SESRQ_F5_SPARSE
-#define SESRQ_F5_SPARSE 1     /* A/B knob: 0 = the hybrid first layer on dense MFMAs (two per chain) */
-#endif
-#ifndef SESRQ_F5_UNROLL
-#define SESRQ_F5_UNROLL 0     /* A/B knob: 1 = the three 4-row groups of a first-layer tile as one basic block */
-#endif
-#ifndef SESRQ_F5_TH
-#define SESRQ_F5_TH 12     /* 12 rows: 8 is 1.3 us faster alone (shorter prologue), 12 and 16 re-quantise fewer halo pixels; with two frames in flight 12 gave +1 % (same-box A/B, round 2) */
-#endif
-constexpr int F5_TH = SESRQ_F5_TH;      // first-layer tile height (rows)
+constexpr int F5_TH = 12;      // first-layer tile height (rows): 8 is 1.3 us faster alone (shorter prologue), 12 and 16 re-quantise fewer halo pixels; with two frames in flight 12 gave +1 % (same-box A/B, round 2)
 constexpr int F5_SH = F5_TH + 4;
 constexpr int F5_SWP = MTW + 8;         // staged pixel columns (2 halo + 64 + 2 halo + over-read)
 constexpr int F5_PITCH = F5_SH + 2;     // LDS column pitch in dwords (>= rows, = 2 mod 4)
@@ -897,11 +845,7 @@ __device__ __forceinline__ void mfma_f5_body(const ConvArgs &a, int4 *buf0, int4
         typedef const int __attribute__((address_space(3))) *lds_int_t;
         const unsigned tb = (unsigned)(size_t)(const __attribute__((address_space(3))) void *)cp;     // LDS byte address of the tile
         unsigned b0 = tb + addr0, b1 = tb + addr1;
-#if SESRQ_F5_UNROLL
-#pragma unroll
-#else
 #pragma unroll 1
-#endif
         for (int y4 = 0; y4 < F5_TH; y4 += 4) {
             int s4[4][4];
 #pragma unroll
@@ -946,11 +890,11 @@ __device__ __forceinline__ void mfma_f5_body(const ConvArgs &a, int4 *buf0, int4
                 }
             }
             // no separate residual tensor <=> zero[1] == -128 (sesrq_create) <=> this layer's z_next == -128: the cvt_pk_u8 epilogue
-            if constexpr (!RC && SESRQ_U8 && BIASED) {      // wave-uniform: the one-fma requant where (M, n) passed its proof
+            if constexpr (!RC && BIASED) {      // wave-uniform: the one-fma requant where (M, n) passed its proof
                 if (a.direct) emit_rows4<EPI_MID, RC, BIASED, 2>(s4, a, io, y4, zlo);
                 else emit_rows4<EPI_MID, RC, BIASED, 1>(s4, a, io, y4, zlo);
             } else {
-                emit_rows4<EPI_MID, RC, BIASED, (!RC && SESRQ_U8) ? 1 : 0>(s4, a, io, y4, zlo);
+                emit_rows4<EPI_MID, RC, BIASED, !RC ? 1 : 0>(s4, a, io, y4, zlo);
             }
             b0 += 16; b1 += 16;
         }
@@ -967,10 +911,7 @@ __device__ __forceinline__ void mfma_f5_body(const ConvArgs &a, int4 *buf0, int4
 // first output word was garbage in lanes 28..31 (caught by the satw_zeros golden vectors; the same source without the
 // attribute, or with unrelated extra code in the loop, is correct) -- those take the registers they ask for.
 template <int MODE, int SRC, bool RC, int NCH, int RR = 4>
-#ifndef SESRQ_F5_WAVES
-#define SESRQ_F5_WAVES 4
-#endif
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SESRQ_F5_WAVES))) void mfma_f5_kernel_w4(const ConvArgs a) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void mfma_f5_kernel_w4(const ConvArgs a) {
     __shared__ int4 buf0[(F5_SWP * F5_PITCH + 3) / 4], buf1[(F5_SWP * F5_PITCH + 3) / 4];      // SH rows of 4-byte pixels
     mfma_f5_body<MODE, SRC, RC, NCH, RR>(a, buf0, buf1);
 }
@@ -1006,9 +947,6 @@ static void launch(K kern, ConvArgs a, hipStream_t st, int tile_h = MTH) {
         }
         blocks_per_cu = it->second;
     }
-    // experiment knobs (read once): a budget of its own for the first layer (tile height 12) / the other per-layer kernels, when the net has one
-    static const int wg_f5 = env_knob("SESRQ_WG_F5", 0, 1, 1 << 16), wg_h = env_knob("SESRQ_WG_H5", 0, 1, 1 << 16);
-    if (a.wg_budget > 0) { if (tile_h == F5_TH && wg_f5 > 0) a.wg_budget = wg_f5; else if (tile_h != F5_TH && wg_h > 0) a.wg_budget = wg_h; }
     const int strips = (a.W + MTW - 1) / MTW, row_tiles = (a.H + tile_h - 1) / tile_h;
     long long k = (a.wg_budget > 0 ? (long long)a.wg_budget : (long long)blocks_per_cu * num_cu) / ((long long)strips * a.N);
     k = std::max(1LL, std::min<long long>(k, row_tiles));
@@ -1113,7 +1051,7 @@ int launch_mfma(const LayerPlan &lp, const ConvArgs &a_in, int src, int epi, boo
 #define SESRQ_F5(...)                                                                    \
     do {                                                                                 \
         if (mode == MERGED) launch(mfma_f5_kernel_w4<MERGED, __VA_ARGS__>, a, st, F5_TH);       \
-        else if (mode == HYB && a.afrag_sp && SESRQ_F5_SPARSE) launch_f5_sparse<__VA_ARGS__>(a, st);        \
+        else if (mode == HYB && a.afrag_sp) launch_f5_sparse<__VA_ARGS__>(a, st);        \
         else if (mode == HYB) launch(mfma_f5_kernel_w4<HYB, __VA_ARGS__>, a, st, F5_TH);        \
         else if (mode == GEN_STD) launch(mfma_f5_kernel<GEN_STD, __VA_ARGS__>, a, st, F5_TH);   \
         else launch(mfma_f5_kernel<GEN_ANY, __VA_ARGS__>, a, st, F5_TH);                        \

@@ -9,26 +9,6 @@ typedef unsigned v4u __attribute__((ext_vector_type(4)));
 typedef unsigned v2u __attribute__((ext_vector_type(2)));
 typedef float v2f __attribute__((ext_vector_type(2)));
 
-#ifndef SESRQ_DIRECT_ROWS
-#define SESRQ_DIRECT_ROWS 0    /* A/B knob: 1 = hidden-layer rows leave (and the residual operand arrives) as one dword per lane and row
-                                  (lane (n, g) owns word g of pixel n: 256 contiguous bytes per wave) instead of 4x4 lane-group transposes
-                                  around one 16-byte access per lane.  Measured round 3 (same box, 3 rounds): 8 v_permlane*_swap fewer per
-                                  four rows, but four times the store / load instructions: first layer 18.9 -> 20.0 us, trio 37.3 -> 39.7 us,
-                                  14.45 k -> 14.1 k frames/s.  Not used. */
-#endif
-#ifndef SESRQ_LUT_BYTES
-#define SESRQ_LUT_BYTES 1     /* A/B knob (one-fma residual merge): 0 = med3 + rounding-constant add, address = float bits + rc byte */
-#endif
-#ifndef SESRQ_U8
-#define SESRQ_U8 1      /* A/B knob: 0 = med3 + magic add + perm epilogue everywhere (round_pack), 1 = round_pack_u8 where every zero point is -128 */
-#endif
-
-#ifndef SESRQ_UNPACK
-#define SESRQ_UNPACK 1     /* round 4: 1 = the one-fma requants as four v_fma_f32 with all-VGPR operands instead of two v_pk_fma_f32 (tools/coissue2_probe.hip) */
-#endif
-#ifndef SESRQ_SER
-#define SESRQ_SER 0        /* experiment (round 4): 1 = a scheduling barrier behind every row: chain, then its epilogue, no interleaving with the next row's chain */
-#endif
 constexpr float MAGIC = 12582912.f;   // 1.5 * 2^23
 
 // accumulate modes
@@ -61,26 +41,16 @@ __device__ __forceinline__ int med3_biased(int v, int lo, int hi) {
 __device__ __forceinline__ v4i ld_frag(const int4 *p) { const int4 t = *p; v4i r = {t.x, t.y, t.z, t.w}; return r; }
 __device__ __forceinline__ unsigned fbits(float f) { return __builtin_bit_cast(unsigned, f); }
 
-// x / s of the input quantiser, three instructions, NO test of fd.ok: the MFMA first-layer kernels run only when sesrq_create
-// selected this form (fd.ok == 1; otherwise sesrq_api.hip sends layer 0 to the dot4 kernel, which divides) -- a wave-uniform
-// test per value cut the staging code into 280 small blocks and cost the first layer 5 % (24.8 -> 23.5 us at 1080p).
-// The reciprocal form (option exact_div = 2) rides on the same instructions with r2 = 0: fma(e, 0, q) == q for the finite e
-// the clamped x gives.
-__device__ __forceinline__ float quotient_in(float x, float s, const FastDiv &fd) {
-    const float xc = med3(x, fd.xlo, fd.xhi);
-    const float q = __fmul_rn(xc, fd.r);
-    return __builtin_fmaf(__builtin_fmaf(-s, q, xc), fd.r2, q);
-}
-// input quantiser q0 = clamp8(rint(fl(fl(x/s) + z)))  (myQL/quan_func.py:225) as the low byte (two's complement) of the
-// returned word: round to nearest even by adding 1.5 * 2^23 -- no v_rndne / v_cvt_i32 -- and NO clamp of the result: quotient_in
-// clamped x to [fd.xlo, fd.xhi], whose ends quantise to exactly -128 and 127 (sesrq_verify.hip proves the whole range, unclamped)
-__device__ __forceinline__ unsigned quantize_in_bits(float x, float s, float z, const FastDiv &fd) {
-    return __builtin_bit_cast(unsigned, __fadd_rn(__fadd_rn(quotient_in(x, s, fd), z), 12582912.f));
-}
-
-// The same with every constant in a VGPR (InQuantV, filled once per kernel through in_vgpr()): a scalar-operand v_mul / v_fma /
-// v_add costs 2.1-2.3 ns per wave on gfx950, the all-VGPR form 1.4-1.5 (tools/op_cost_probe.hip) -- five such instructions per
-// value -- and v_med3 with two wave-uniform bounds needs one of them in a VGPR anyway (one SGPR per instruction).
+// Input quantiser q0 = clamp8(rint(fl(fl(x/s) + z)))  (myQL/quan_func.py:225) as the low byte (two's complement) of the returned word.
+// x / s is formed in three instructions, q = xc * r, fma(fma(-s, q, xc), r2, q), with NO test of fd.ok: the MFMA first-layer kernels run
+// only when sesrq_create selected this form (fd.ok == 1; otherwise sesrq_api.hip sends layer 0 to the dot4 kernel, which divides) -- a
+// wave-uniform test per value cut the staging code into 280 small blocks and cost the first layer 5 % (24.8 -> 23.5 us at 1080p).  The
+// reciprocal form (option exact_div = 2) rides on the same instructions with r2 = 0: fma(e, 0, q) == q for the finite e the clamped x
+// gives.  Round to nearest even by adding 1.5 * 2^23 -- no v_rndne / v_cvt_i32 -- and NO clamp of the result: x is clamped to
+// [xlo, xhi], whose ends quantise to exactly -128 and 127 (sesrq_verify.hip proves the whole range, unclamped).
+// Every constant sits in a VGPR (InQuantV, filled once per kernel through pin()): a scalar-operand v_mul / v_fma / v_add costs
+// 2.1-2.3 ns per wave on gfx950, the all-VGPR form 1.4-1.5 (tools/op_cost_probe.hip) -- five such instructions per value -- and v_med3
+// with two wave-uniform bounds needs one of them in a VGPR anyway (one SGPR per instruction).
 struct InQuantV { float xlo, xhi, r, ns, r2, z, magic; };
 __device__ __forceinline__ unsigned quantize_in_bits(float x, const InQuantV &c) {
     const float xc = med3(x, c.xlo, c.xhi);
@@ -168,20 +138,14 @@ __device__ __forceinline__ unsigned round_pack_u8(v2f v01, v2f v23) {
     return flip80(w);
 }
 
-// w[i] = fma(bits(s[i]), M, c) for four biased sums: packed (two v_pk_fma_f32) or unpacked (four v_fma_f32, every operand a VGPR)
+// w[i] = fma(bits(s[i]), M, c) for four biased sums, as four v_fma_f32 whose operands are ALL VGPRs (in_vgpr): round 3 issued two
+// v_pk_fma_f32 with a scalar M.  Measured round 4 (tools/coissue2_probe.hip, tools/coissue3_probe.hip): beside MFMAs a packed fp32
+// instruction costs 6.6 cycles of the SIMD (3.3 per value), a plain VALU instruction 2.1 from another wave and 3.4 from the MFMA's
+// own wave; same-box A/B: trio -2.4 %, last layer -3.3 %.
 __device__ __forceinline__ void fma4_biased(const int s[4], float Md, float Cd, float w[4]) {
-    const float cv = in_vgpr(Cd);
-#if SESRQ_UNPACK
-    const float mv = in_vgpr(Md);
+    const float cv = in_vgpr(Cd), mv = in_vgpr(Md);
 #pragma unroll
     for (int i = 0; i < 4; ++i) w[i] = __builtin_fmaf(__builtin_bit_cast(float, s[i]), mv, cv);
-#else
-    const v2f M2 = {Md, Md}, c2 = {cv, cv};
-    const v2f y01 = {__builtin_bit_cast(float, s[0]), __builtin_bit_cast(float, s[1])};
-    const v2f y23 = {__builtin_bit_cast(float, s[2]), __builtin_bit_cast(float, s[3])};
-    const v2f v01 = __builtin_elementwise_fma(y01, M2, c2), v23 = __builtin_elementwise_fma(y23, M2, c2);
-    w[0] = v01[0]; w[1] = v01[1]; w[2] = v23[0]; w[3] = v23[1];
-#endif
 }
 
 // ---- epilogues (AT = any struct with the ConvArgs field names Mf, sh, z_next, Mres, shres, z_merge) ----
@@ -246,7 +210,7 @@ __device__ __forceinline__ unsigned epi_preres(const int s[4], unsigned rcword, 
 // (ulp 1), its low 16 bits are lut_addr + (ic + 256), and adding the signed rc byte to them (one v_add_u32_sdwa) IS the LDS address
 // of q4(u): per value 2 fma + med3 + add + sdwa-add + one byte read (+ 1/4 v_lshl_or), no second requant, no byte shuffles.
 // ONE_FMA (prove_direct_requant for this layer's (M, n)): w = fl(s * M) * 2^-n out of one fma, ic + 128 = rint(clamp(w, 0, 255)) --
-// the "- 128" moves from the requant into the rounding constant (lut_magic - 128): one pk_fma per two values less.
+// the table index is then the sum of two unsigned bytes (below).
 template <bool BIASED, bool ONE_FMA = false, class AT>
 __device__ __forceinline__ unsigned epi_preres_lut(const int s[4], unsigned rcword, const AT &a, float lut_magic,
                                                    const unsigned char __attribute__((address_space(3))) *lut = nullptr) {
@@ -258,7 +222,6 @@ __device__ __forceinline__ unsigned epi_preres_lut(const int s[4], unsigned rcwo
         float t[4];
         fma4_biased(s, a.Md, a.Cd, t);
         v01 = (v2f){t[0], t[1]}; v23 = (v2f){t[2], t[3]};
-#if SESRQ_LUT_BYTES
         // ic + 128 as four bytes of one word (cvt_pk_u8: clamp, rounding and insertion in one instruction per value), rc + 128 by one
         // xor per word; u = the sum of two unsigned bytes (v_add_u32_sdwa, BYTE_k + BYTE_k) IS the table index, the table's LDS address
         // rides in the read's offset field: 4 cvt + 1/4 xor instead of 4 med3 + 2 pk_add per four values
@@ -277,12 +240,6 @@ __device__ __forceinline__ unsigned epi_preres_lut(const int s[4], unsigned rcwo
         const v2us_ x_ = {(unsigned short)lut[u0], (unsigned short)lut[u2]};
         const v2us_ y_ = {(unsigned short)lut[u1], (unsigned short)lut[u3]};
         return __builtin_bit_cast(unsigned, x_) | (__builtin_bit_cast(unsigned, y_) << 8);
-#else
-        const float m128 = lut_magic - 128.f;                  // MAGIC + 128 + lut_addr (exact): low 16 bits of c = lut_addr + (ic + 128) + 128
-        const v2f mg = {m128, m128};
-        c01 = (v2f){med3(v01[0], 0.f, 255.f), med3(v01[1], 0.f, 255.f)}; c23 = (v2f){med3(v23[0], 0.f, 255.f), med3(v23[1], 0.f, 255.f)};
-        c01 = c01 + mg; c23 = c23 + mg;
-#endif
     } else {
         requant4<BIASED>(s, a.Mf, a.sh, -128.f, v01, v23);
         const v2f mg = {lut_magic, lut_magic};                 // MAGIC + 256 + lut_addr: the low 16 bits of c are lut_addr + (ic + 256)
@@ -363,7 +320,6 @@ __device__ __forceinline__ void transpose4(unsigned w[4]) {
 struct RowIO {
     __amdgpu_buffer_rsrc_t out, rc_in, rc_out;
     int voff;        // lane (n, r' = g): byte offset of pixel (y0 + g, gx) or out-of-range
-    int voffw;       // lane (n, g): byte offset of word g of pixel (y0, gx) or out-of-range
     int row_bytes;   // W * 16
 };
 __device__ __forceinline__ RowIO make_rowio(const ConvArgs &a, int n_img, int y0, int gx, int g) {
@@ -375,18 +331,11 @@ __device__ __forceinline__ RowIO make_rowio(const ConvArgs &a, int n_img, int y0
     io.rc_out = __builtin_amdgcn_make_buffer_rsrc((char *)a.rc_out + (size_t)n_img * img, 0, bytes, 0x00020000);
     io.row_bytes = a.W * 16;
     io.voff = (gx < a.W) ? ((y0 + g) * a.W + gx) * 16 : (int)0x80000000;
-    io.voffw = (gx < a.W) ? (y0 * a.W + gx) * 16 + 4 * g : (int)0x80000000;
     return io;
 }
 __device__ __forceinline__ void store_rows4(__amdgpu_buffer_rsrc_t rs, const RowIO &io, int y4, unsigned w[4]) {
     // aux 16 = sc1: the activation tensor is only read again by the NEXT kernel; measured against the default policy,
     // sc0|sc1 and nt on 1080p: sc1 -6 % on the first layer, -3..5 % on the hidden layers when frames overlap; nt +12 %
-    if constexpr (SESRQ_DIRECT_ROWS) {
-        // compute layout straight to memory: one dword per lane and row (64 lanes = 16 pixels x 4 words = two full 128-byte lines)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) __builtin_amdgcn_raw_buffer_store_b32(w[r], rs, io.voffw + (y4 + r) * io.row_bytes, 0, 16);
-        return;
-    }
     transpose4(w);
     const v4u v = {w[0], w[1], w[2], w[3]};
     // The row offset rides in the VECTOR offset, soffset = 0, on purpose: gfx950 needs one wait state between a dwordx4 store with
@@ -403,14 +352,9 @@ __device__ __forceinline__ void emit_rows4(const int s4[4][4], const AT &a, cons
     unsigned w[4];
     if constexpr (EPI == EPI_PRERES) {
         unsigned rcw[4];
-        if constexpr (SESRQ_DIRECT_ROWS) {       // the residual operand in compute layout: word g of pixel n, one dword per row
-#pragma unroll
-            for (int r = 0; r < 4; ++r) rcw[r] = __builtin_amdgcn_raw_buffer_load_b32(io.rc_in, io.voffw + (y4 + r) * io.row_bytes, 0, 0);
-        } else {
-            const v4u rv = __builtin_amdgcn_raw_buffer_load_b128(io.rc_in, io.voff, y4 * io.row_bytes, 0);
-            rcw[0] = rv[0]; rcw[1] = rv[1]; rcw[2] = rv[2]; rcw[3] = rv[3];
-            transpose4(rcw);
-        }
+        const v4u rv = __builtin_amdgcn_raw_buffer_load_b128(io.rc_in, io.voff, y4 * io.row_bytes, 0);
+        rcw[0] = rv[0]; rcw[1] = rv[1]; rcw[2] = rv[2]; rcw[3] = rv[3];
+        transpose4(rcw);
 #pragma unroll
         for (int r = 0; r < 4; ++r) w[r] = epi_preres<BIASED, (U8 != 0)>(s4[r], rcw[r], a);
     } else {

@@ -23,13 +23,6 @@
 #include <mutex>
 #include <type_traits>
 
-#ifndef SESRQ_TRIO_LUT
-#define SESRQ_TRIO_LUT 1        /* A/B knob: 0 = the residual merge's second requant in arithmetic instead of the LDS table */
-#endif
-#ifndef SESRQ_TRIO_NOPAD
-#define SESRQ_TRIO_NOPAD 1      /* A/B knob: 0 = the inner phases always run their per-row pad select */
-#endif
-
 #include "sesrq_mfma_common.h"
 
 namespace sesrq {
@@ -111,7 +104,7 @@ __global__ __launch_bounds__(256) void mfma_trio_kernel(const TrioArgs a) {
     // IS an LDS address (no base to add per lookup); the three windows are the dynamic part behind it
     __shared__ int4 trio_lut[TRIO_LUT_I4];
     int4 *lutp = trio_lut, *bufI = trio_lds, *bufA = bufI + TRIO_WIN, *bufB = bufI + 2 * TRIO_WIN;
-    constexpr bool LUT = EPI_C == EPI_PRERES && SESRQ_TRIO_LUT;
+    constexpr bool LUT = EPI_C == EPI_PRERES;
     constexpr bool RCW = LUT && (U8 & 8) != 0;
     // MAGIC + 256 + the table's LDS byte address (exact: < 2^24); see epi_preres_lut
     const float lut_magic = MAGIC + 256.f + (float)(unsigned)(size_t)(const __attribute__((address_space(3))) void *)lutp;
@@ -171,16 +164,9 @@ __global__ __launch_bounds__(256) void mfma_trio_kernel(const TrioArgs a) {
         const int4 *p = src + rdcol;
         unsigned *d = reinterpret_cast<unsigned *>(dst) + wrcol;
         v4i B0 = ld_frag(p + (i0)*TP), B1 = ld_frag(p + (i0 + 1) * TP);
-        v4i Bn = ld_frag(p + (i0 + 2) * TP);
 #pragma unroll
         for (int i = i0; i < i1; ++i) {
-            v4i B2;
-            if constexpr ((SESRQ_SER & 8) != 0) {       // the next row's new operand is requested a whole row ahead of its chain
-                B2 = Bn;
-                if (i + 1 < i1) Bn = ld_frag(p + (i + 3) * TP);
-            } else {
-                B2 = ld_frag(p + (i + 2) * TP);
-            }
+            const v4i B2 = ld_frag(p + (i + 2) * TP);
             v4i acc = mfma(A[K][0], B0, acc0[K]);
             acc = mfma(A[K][1], B1, acc);
             acc = mfma(A[K][2], B2, acc);
@@ -193,7 +179,6 @@ __global__ __launch_bounds__(256) void mfma_trio_kernel(const TrioArgs a) {
                 q = (rok & col_in) ? q : (unsigned)L.pad_next;
             }
             d[(2 + i) * TP * 4] = q;
-            if constexpr ((SESRQ_SER & 1) != 0) __builtin_amdgcn_sched_barrier(0);
         }
     };
     // outer layer: output rows Y .. Y+NR-1 (NR = 8, or 4 in a half step) from window positions 0 .. NR+1 of layer b
@@ -212,7 +197,6 @@ __global__ __launch_bounds__(256) void mfma_trio_kernel(const TrioArgs a) {
         constexpr int NR = decltype(NRC)::value;
         const int4 *p = bufB + rdcol;
         io.voff = col_out ? voff_c + Y * io.row_bytes : OOB;
-        io.voffw = col_out ? gx * 16 + 4 * g + Y * io.row_bytes : OOB;
         v4i B0 = ld_frag(p), B1 = ld_frag(p + TP);
 #pragma unroll
         for (int y4 = 0; y4 < NR; y4 += 4) {
@@ -226,9 +210,7 @@ __global__ __launch_bounds__(256) void mfma_trio_kernel(const TrioArgs a) {
                 B0 = B1; B1 = B2;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) s4[r][i] = acc[i];
-                if constexpr ((SESRQ_SER & 4) != 0) __builtin_amdgcn_sched_barrier(0);
             }
-            if constexpr ((SESRQ_SER & 2) != 0) __builtin_amdgcn_sched_barrier(0);
             if constexpr (LUT) {
                 const v4u rv = rcp[y4 / 4];
                 unsigned rcw[4] = {rv[0], rv[1], rv[2], rv[3]}, wq[4];
@@ -240,7 +222,6 @@ __global__ __launch_bounds__(256) void mfma_trio_kernel(const TrioArgs a) {
             } else {
                 emit_rows4<EPI_C, false, true, (U8 & 4) ? 2 : (U8 & 1)>(s4, ec, io, y4, a.l[2].zlo);
             }
-            if constexpr ((SESRQ_SER & 2) != 0) __builtin_amdgcn_sched_barrier(0);
         }
     };
     // RCW: the residual operand of frame row (window position pos) of this lane's output pixel, straight from the input window
@@ -294,7 +275,7 @@ __global__ __launch_bounds__(256) void mfma_trio_kernel(const TrioArgs a) {
         shift(bufB);                                             // layer-b rows Y-1, Y (phase c of the previous step is done)
         v4u rcp[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
         if constexpr (RCW) rc_from_window(IC8(), rcp);           // bufI = rows Y+1 .. Y+10 until the first barrier
-        const bool nopad = SESRQ_TRIO_NOPAD && strip_in && (Y + TH + 2 <= a.H);      // wave-uniform: rows Y+1 .. Y+9, all 64 columns inside
+        const bool nopad = strip_in && (Y + TH + 2 <= a.H);      // wave-uniform: rows Y+1 .. Y+9, all 64 columns inside
         if (nopad) inner(IC0(), IC0(), IC8(), bufI, bufA, Y + 2, std::false_type());
         else inner(IC0(), IC0(), IC8(), bufI, bufA, Y + 2, std::true_type());
         int4 shI = make_int4(0, 0, 0, 0);
@@ -331,19 +312,15 @@ __global__ __launch_bounds__(256) void mfma_trio_kernel(const TrioArgs a) {
 // strip is cut into floor(occ * CUs / (strips * N)) runs whose lengths differ by at most one step.
 template <typename K>
 static void launch_trio_k(K kern, TrioArgs a, hipStream_t st) {
-    // tuning knobs, read once: workgroups per CU (3 or 4: the LDS sizes a plain launch accepts and the kernel's registers allow),
-    // rows per partition unit (4 / 8, 0 = by run length)
-    static const int occ = env_knob("SESRQ_TRIO_OCC", 4, 3, 4), unit_knob = env_knob("SESRQ_TRIO_UNIT", 0, 4, 8);
+    // 4 workgroups per CU: the LDS size a plain launch accepts and the kernel's registers allow (3 and 5 measured slower, rounds 2-3)
+    constexpr int occ = 4;
     const int num_cu = device_cu_count();
     const int lds = std::max(TRIO_LDS_BYTES, ((160 * 1024 / occ) & ~1023) - TRIO_LUT_I4 * 16);      // static + dynamic: exactly occ workgroups per 160 KiB
     const int strips = (a.W + TV - 1) / TV, steps = (a.H + TH - 1) / TH;
-    static const int wg_trio = env_knob("SESRQ_WG_TRIO", 0, 1, 1 << 16);      // experiment knob: a budget of its own for the trio, when the net has one
-    if (a.wg_budget > 0 && wg_trio > 0) a.wg_budget = wg_trio;
     long long k = (a.wg_budget > 0 ? (long long)a.wg_budget : (long long)occ * num_cu) / ((long long)strips * a.N);
     k = std::max(1LL, std::min<long long>(k, steps));                     // a run is at least one full step on average
     a.chunk_steps = (int)((steps + k - 1) / k);
     a.run_unit = (steps < 3 * k) ? TH / 2 : TH;                           // short runs (< 3 steps) are cut in half-step units
-    if (unit_knob == 4 || unit_knob == 8) a.run_unit = unit_knob;
     dim3 grid(strips, (int)k, a.N);
     launch_kernel(kern, grid, dim3(256), (unsigned)lds, st, a);
 }
@@ -354,12 +331,10 @@ int launch_trio(const TrioArgs &a, int epi_c, hipStream_t st) {
     bool u8 = a.l[0].z_next == -128.f && a.l[1].z_next == -128.f && a.l[0].zlo == -128.f && a.l[1].zlo == -128.f;
     if (epi_c == EPI_PRERES) u8 = u8 && a.z_merge == -128.f;
     else u8 = u8 && a.l[2].z_next == -128.f && a.l[2].zlo == -128.f;
-    if (!SESRQ_U8) u8 = false;                     // A/B build knob
     const bool ab = u8 && a.l[0].direct && a.l[1].direct, abc = ab && a.l[2].direct;      // one-fma requants (proof per layer)
     const int mode = abc ? 7 : (ab ? 3 : (u8 ? 1 : 0));
-    static const int rcw_knob = env_knob("SESRQ_TRIO_RCW", 1, 0, 1);
     if (epi_c == EPI_PRERES) {
-        if (mode == 7 && a.rc_in == a.in && rcw_knob && SESRQ_TRIO_LUT) launch_trio_k(mfma_trio_kernel<EPI_PRERES, 15>, a, st);      // the residual operand out of the input window
+        if (mode == 7 && a.rc_in == a.in) launch_trio_k(mfma_trio_kernel<EPI_PRERES, 15>, a, st);      // the residual operand out of the input window
         else if (mode == 7) launch_trio_k(mfma_trio_kernel<EPI_PRERES, 7>, a, st);
         else if (mode == 3) launch_trio_k(mfma_trio_kernel<EPI_PRERES, 3>, a, st);
         else if (mode == 1) launch_trio_k(mfma_trio_kernel<EPI_PRERES, 1>, a, st);

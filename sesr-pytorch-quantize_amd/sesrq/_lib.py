@@ -16,7 +16,7 @@ MAX_LAYERS = 16
 MAX_CH = 16
 F32, I8 = 0, 1
 ENGINE_AUTO, ENGINE_DOT4, ENGINE_MFMA = 0, 1, 2
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 
 class LayerDesc(C.Structure):
@@ -44,6 +44,10 @@ class CalibConvDesc(C.Structure):
                 ("acc_hi", C.c_float), ("add_lo", C.c_float), ("add_hi", C.c_float), ("relu", C.c_int32)]
 
 
+class FrameIO(C.Structure):
+    _fields_ = [("inp", C.c_void_p), ("out_q", C.c_void_p), ("out_f", C.c_void_p)]
+
+
 class Taps(C.Structure):
     _fields_ = [("act", C.c_void_p * MAX_LAYERS), ("pe_out", C.c_void_p * MAX_LAYERS),
                 ("pe_add", C.c_void_p * MAX_LAYERS), ("overflow", C.c_void_p)]
@@ -61,6 +65,8 @@ SYMBOLS = {
     "sesrq_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_int, C.c_int, C.c_int]),
     "sesrq_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                 C.c_void_p, C.c_size_t, C.c_void_p]),
+    "sesrq_forward_many": (C.c_int, [C.c_void_p, C.POINTER(FrameIO), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                     C.POINTER(C.c_void_p), C.c_size_t, C.POINTER(C.c_void_p), C.c_int]),
     "sesrq_forward_debug": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
                                       C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.POINTER(Taps)]),
     "sesrq_forward_timed": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int,

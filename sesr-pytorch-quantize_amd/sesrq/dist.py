@@ -27,13 +27,15 @@ def shard(num_frames: int, world: int, rank: int) -> range:
 HOST_SAMPLE = 16      # untimed steps behind the warm-up on which the host's enqueue time per step is measured
 
 
-def run_timed(group: "Group", step, steps: int, warmup: int, repeats: int = 1, sync=None, units_per_step: float = 1.0):
+def run_timed(group: "Group", step, steps: int, warmup: int, repeats: int = 1, sync=None, units_per_step: float = 1.0, step_many=None):
     """The measurement loop of bench.py, shared with the CPU tests so that on a multi-GPU node the RCCL backend is
     the only line that has not run before:  W untimed warm-up steps, then `repeats` blocks of EXACTLY `steps` steps,
     each block bracketed by  sync() -> barrier  on both sides (local queue drained first, then the rendezvous, so every
     rank starts its clock with an idle device and stops it when ITS work is done and all ranks have arrived); the
     block's time is the MAX over ranks.  `units_per_step` = units (frames) THIS rank processes per step; the job's
     rate is the sum over ranks of units / the max-over-ranks time.  No data-path collective.
+    step_many(n), if given, enqueues n consecutive steps with ONE call (sesrq_forward_many): every phase then hands its steps over in one
+    piece -- W, then HOST_SAMPLE, then exactly K per block; step() is not used.
 
     Returns {"elapsed": [s per block], "units_per_step_total": sum over ranks, "rates": [units/s per block],
     "host_enqueue_s_per_step": host time to enqueue one step, measured on HOST_SAMPLE untimed steps behind the warm-up, queue drained first}."""
@@ -47,19 +49,25 @@ def run_timed(group: "Group", step, steps: int, warmup: int, repeats: int = 1, s
     # W warm-up steps, untimed.  Then -- still untimed, whatever W is -- HOST_SAMPLE more steps whose ENQUEUE time on the host is read
     # off with the device queue drained first (so the queue's back-pressure does not enter: the loop does not wait); they run on a
     # warm process (round 3 sampled warm-up steps 3..5 under --warmup 5 and read the lazy initialisation: 52.7 us vs 18-19)
-    for _ in range(warmup):
-        step()
+    def run(n):
+        if n <= 0:
+            return
+        if step_many is not None:
+            step_many(n)
+        else:
+            for _ in range(n):
+                step()
+
+    run(warmup)
     sync()
     tw = time.perf_counter()
-    for _ in range(HOST_SAMPLE):
-        step()
+    run(HOST_SAMPLE)
     host_s = (time.perf_counter() - tw) / HOST_SAMPLE
     elapsed = []
     for _ in range(max(1, repeats)):
         fence()
         t0 = time.perf_counter()
-        for _ in range(steps):
-            step()
+        run(steps)
         fence()
         elapsed.append(group.max_over_ranks(time.perf_counter() - t0))
     total_units = group.sum_over_ranks(units_per_step)

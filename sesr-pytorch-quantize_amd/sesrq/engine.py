@@ -59,6 +59,51 @@ class GraphedForward:
         return self.q, self.y
 
 
+class Submission:
+    """Frames, buffers and streams of Engine.submission(), laid out once as the C arrays sesrq_forward_many takes."""
+
+    def __init__(self, engine, frames, outs_q, outs_f, streams):
+        if not frames or not streams or len(frames) != len(outs_q) or (outs_f is not None and len(outs_f) != len(frames)):
+            raise ValueError("submission: frames / outputs / streams do not match")
+        if len(frames) % len(streams):
+            raise ValueError("submission: the frame list must be a multiple of the stream count (frame k runs on stream k % S, cyclically)")
+        self.engine, self.n = engine, len(frames)
+        self.dt = engine._check_in(frames[0])
+        N, _, H, W = frames[0].shape
+        self.shape = (N, H, W)
+        shp = engine.out_shape(N, H, W)
+        for k, x in enumerate(frames):
+            if engine._check_in(x) != self.dt or tuple(x.shape) != tuple(frames[0].shape) or not x.is_contiguous():
+                raise ValueError("submission: every frame must be a contiguous tensor of the same shape and dtype")
+            if tuple(outs_q[k].shape) != tuple(shp) or outs_q[k].dtype != torch.int8 or not outs_q[k].is_contiguous():
+                raise ValueError("submission: every int8 output must be a contiguous tensor of the forward's output shape")
+        self._keep = (list(frames), list(outs_q), list(outs_f) if outs_f is not None else None, list(streams))
+        # two periods back to back: any window of up to n frames starting anywhere in the cycle is one contiguous slice
+        self.io = (_lib.FrameIO * (2 * self.n))()
+        for k in range(2 * self.n):
+            j = k % self.n
+            self.io[k] = _lib.FrameIO(frames[j].data_ptr(), outs_q[j].data_ptr(), outs_f[j].data_ptr() if outs_f is not None else None)
+        S = len(streams)
+        self.ws = [engine.workspace(N, H, W, s) for s in range(S)]
+        self.ws_bytes = self.ws[0].numel()
+        # the library maps frame k of a call to streams[k % S]: a window that starts at frame f of the list gets the arrays rotated by f % S
+        self.ws_rot = [(C.c_void_p * S)(*[self.ws[(r + i) % S].data_ptr() for i in range(S)]) for r in range(S)]
+        self.st_rot = [(C.c_void_p * S)(*[streams[(r + i) % S].cuda_stream for i in range(S)]) for r in range(S)]
+        self.S = S
+
+    def enqueue(self, count: int, first: int = 0):
+        """Frames first .. first+count-1 (indices taken modulo the list): sesrq_forward_many calls of at most one period each."""
+        lib, N, (n, H, W) = _lib.lib(), self.n, self.shape
+        k, base, sz = first, C.addressof(self.io), C.sizeof(_lib.FrameIO)
+        while count > 0:
+            c = min(count, N)
+            off = k % N
+            _lib.check(lib.sesrq_forward_many(self.engine._h, C.cast(base + off * sz, C.POINTER(_lib.FrameIO)), c, self.dt, n, H, W,
+                                              self.ws_rot[off % self.S], self.ws_bytes, self.st_rot[off % self.S], self.S))
+            k += c
+            count -= c
+
+
 class Engine:
     """One immutable net on one device.  forward() is stream-ordered and allocation-free once
     the workspace for a given (N, H, W) exists."""
@@ -100,7 +145,7 @@ class Engine:
             raise ValueError("exact_division and reciprocal_division exclude each other")
         opts.exact_div = 2 if reciprocal_division else int(bool(exact_division))
         opts.anchor_add = int(bool(anchor_add))
-        opts.fuse_hidden = 1 if fuse_hidden is True else int(fuse_hidden)     # 0 per layer, 1 (default) hidden trios, 2 + fused front
+        opts.fuse_hidden = 1 if fuse_hidden is True else int(fuse_hidden)     # 0 per layer, 1 (default) fused hidden trios
         opts.wg_budget = int(wg_budget)
         if upstream is not None:
             opts.i8_in_scale = float(np.float32(upstream.scale[upstream.L]))
@@ -220,6 +265,13 @@ class Engine:
         return out_q, out_f
 
     __call__ = forward
+
+    def submission(self, frames, outs_q, streams, outs_f=None):
+        """A prepared batch of independent forwards for sesrq_forward_many: frame k = frames[k] -> outs_q[k] (/ outs_f[k]) on
+        streams[k % len(streams)] with workspace slot k % len(streams).  Returns a Submission; .enqueue(count, first=0) issues frames
+        first .. first+count-1 of the (cyclically repeated) list with ONE call into the library -- for callers whose frames are so small
+        that the host's per-call cost bounds the rate.  Caller-owned persistent buffers; the caller fences the streams."""
+        return Submission(self, frames, outs_q, outs_f, streams)
 
     def capture(self, x: torch.Tensor, want_q: bool = True, want_f: bool = False, slot: int = 0, downstream=()):
         """Capture one forward on `x` (and then, optionally, the chained `downstream` engines on its int8 output) as a HIP

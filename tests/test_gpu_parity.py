@@ -19,10 +19,9 @@ pytestmark = pytest.mark.gpu
 
 STAGE_FILES = [f for f in golden_files() if not f.endswith((".params.npz", "tables.npz", ".stimtxt.npz", ".anchor.npz"))]
 # kernel families behind the same ABI: dot4 (one lane per pixel), mfma (one launch per layer), trio (MFMA kernels with every
-# eligible run of three hidden 3x3 layers fused into one launch: the default), quad (fuse_hidden=2: the first layer fused in
-# front of the residual-merging trio where the net allows it, trios elsewhere)
+# eligible run of three hidden 3x3 layers fused into one launch: the default)
 ENGINES = [("dot4", dict(engine=_lib.ENGINE_DOT4)), ("mfma", dict(engine=_lib.ENGINE_MFMA, fuse_hidden=0)),
-           ("trio", dict(engine=_lib.ENGINE_MFMA, fuse_hidden=1)), ("quad", dict(engine=_lib.ENGINE_MFMA, fuse_hidden=2))]
+           ("trio", dict(engine=_lib.ENGINE_MFMA, fuse_hidden=1))]
 
 
 def make_engine(net, eng, **kw):
@@ -65,11 +64,9 @@ def test_golden_stage_by_stage(path, eng):
         hidden_merged = all(l.M > 0 for l in net.layers) and not any("general" in s_ or "hybrid" in s_ for s_ in
                                                                      sesrq.Engine(bundle_from_oracle(net), _dev(), fuse_hidden=0).layer_engines()[1:4])
         if eng[0] == "mfma":
-            assert not any("trio" in s_ or "quad" in s_ for s_ in names), names
-        elif eng[0] == "trio":
-            assert ("mfma-trio-merged" in names) == hidden_merged and not any("quad" in s_ for s_ in names), names
-        else:       # quad where the first layer is merged / hybrid and zero[1] == -128, else the trio
-            assert any("quad" in s_ or "trio" in s_ for s_ in names) == hidden_merged, names
+            assert not any("trio" in s_ for s_ in names), names
+        else:
+            assert ("mfma-trio-merged" in names) == hidden_merged, names
     r = net.pixel_shuffle
     got = {k: v.cpu().numpy() for k, v in res.items()}
     # un-shuffle q_out to compare with input5
@@ -237,9 +234,8 @@ def test_4k_input_frame_large_offsets():
     x = torch.rand((1, 3, H, W), generator=torch.Generator().manual_seed(9)).to(_dev())
     e = sesrq.Engine(b, _dev())
     q, y = e.forward(x)
-    for fh in (0, 2):
-        q2, _ = sesrq.Engine(b, _dev(), fuse_hidden=fh).forward(x, want_f=False)
-        assert torch.equal(q, q2), fh
+    q2, _ = sesrq.Engine(b, _dev(), fuse_hidden=0).forward(x, want_f=False)
+    assert torch.equal(q, q2)
     zL, sL = net.zero[net.L], np.float32(net.scale[net.L])
     assert torch.equal(y, (q.float() - zL) * float(sL))
     for (y0, x0) in [(0, 0), (0, W - 160), (H - 120, 0), (H - 120, W - 160), (1000, 1900)]:
@@ -277,7 +273,8 @@ def test_error_conventions():
     with pytest.raises(ValueError, match="pe_num"):
         sesrq.Engine(bad, _dev())
     # option values outside their range are refused by sesrq_create (the net would otherwise be built on a guess)
-    for kw, msg in ((dict(fuse_hidden=3), "fuse_hidden"), (dict(fuse_hidden=-1), "fuse_hidden"), (dict(engine=9), "engine")):
+    # (fuse_hidden = 2 was the fused front of rounds 2-3, retired in round 4)
+    for kw, msg in ((dict(fuse_hidden=2), "fuse_hidden"), (dict(fuse_hidden=-1), "fuse_hidden"), (dict(engine=9), "engine")):
         with pytest.raises(ValueError, match=msg):
             sesrq.Engine(b, _dev(), **kw)
     # a scale the reciprocal form cannot represent (1/s0 overflows): exact_div = 2 is refused, the default falls back to the
@@ -342,7 +339,7 @@ def test_reciprocal_division_option_is_the_gpu_run_reference_quantiser():
     want_q, _ = ref.forward(torch.from_numpy(q0r).to(_dev()))                       # an int8 frame IS q0 (test_int8_input_path)
     base_q, _ = ref.forward(xt)
     assert not torch.equal(want_q, base_q)
-    for kw in (dict(engine=_lib.ENGINE_DOT4), dict(fuse_hidden=0), dict(fuse_hidden=1), dict(fuse_hidden=2)):
+    for kw in (dict(engine=_lib.ENGINE_DOT4), dict(fuse_hidden=0), dict(fuse_hidden=1)):
         e = sesrq.Engine(b, _dev(), reciprocal_division=True, **kw)
         assert e.fast_division_proven()                                             # the proof is reported whatever form runs
         if kw.get("engine") == _lib.ENGINE_DOT4:
@@ -449,7 +446,7 @@ def test_config5_shape_nrdm6_then_sesr_x2_chain():
     # int8 hand-off: the second net takes the first one's int8 output and re-quantises it while staging
     # (sesrq_options.i8_in_scale/zero) -- same bits as the fp32 hand-off, a quarter of the bytes, on every first-layer kernel
     q1, _ = e1.forward(torch.from_numpy(x).to(_dev()), want_f=False)
-    for kw in (dict(), dict(fuse_hidden=2), dict(engine=_lib.ENGINE_DOT4)):
+    for kw in (dict(), dict(fuse_hidden=0), dict(engine=_lib.ENGINE_DOT4)):
         e2i = sesrq.Engine(bundle_from_oracle(sr), _dev(), upstream=bundle_from_oracle(nr), **kw)
         q2i, _ = e2i.forward(q1)
         _cmp("chain int8 hand-off", q2i, w2["q_out"])
@@ -596,7 +593,7 @@ def test_randomised_shapes_against_c_oracle():
             w = (net.layers[k].wq.astype(np.int32) // 2).astype(np.int8)
             w[int(rng.integers(w.shape[0])), int(rng.integers(min(4, w.shape[1])))::4] = 127
             net.layers[k].wq = w
-        e = sesrq.Engine(bundle_from_oracle(net), _dev(), fuse_hidden=1 + trial % 2)      # launch plans alternate: trio / fused front
+        e = sesrq.Engine(bundle_from_oracle(net), _dev(), fuse_hidden=trial % 2)      # launch plans alternate: per layer / fused trio
         H, W, N = int(rng.choice(heights)), int(rng.choice(widths)), int(rng.choice([1, 1, 2, 3]))
         x = rng.random((N, net.layers[0].wq.shape[1], H, W), dtype=np.float32)
         want = CO.forward(net, x)
@@ -675,10 +672,8 @@ def test_trio_walk_shapes_and_chunking(budget):
     from oracle import c_oracle as CO
     for seed, kind in enumerate(["sesr_x2", "nrdm", "sesr_x4"]):
         net = O.synth_net(kind, 40 + seed)
-        eq = sesrq.Engine(bundle_from_oracle(net), _dev(), fuse_hidden=2, wg_budget=budget)
         et = sesrq.Engine(bundle_from_oracle(net), _dev(), wg_budget=budget)
         el = sesrq.Engine(bundle_from_oracle(net), _dev(), fuse_hidden=0, wg_budget=budget)
-        assert eq.layer_engines()[:4] == ["mfma-quad-merged"] * 4 and eq.launch_plan() == [(0, 4), (4, 1)]
         assert et.layer_engines()[1:4] == ["mfma-trio-merged"] * 3 and et.launch_plan() == [(0, 1), (1, 3), (4, 1)]
         assert el.launch_plan() == [(k, 1) for k in range(5)]
         cin = net.layers[0].wq.shape[1]
@@ -687,15 +682,13 @@ def test_trio_walk_shapes_and_chunking(budget):
             xt = torch.from_numpy(x).to(_dev())
             q, y = et.forward(xt)
             q2, y2 = el.forward(xt)
-            q3, y3 = eq.forward(xt)
             want = CO.forward(net, x)
-            _cmp(f"{net.name} {N}x{H}x{W} budget {budget}: fused front vs oracle", q3, want["q_out"])
             _cmp(f"{net.name} {N}x{H}x{W} budget {budget}: trio vs oracle", q, want["q_out"])
             _cmp(f"{net.name} {N}x{H}x{W} budget {budget}: per-layer vs oracle", q2, want["q_out"])
-            _cmp("y", y3, want["y"])
-            # the fused front also takes an already-quantised frame (and an upstream net's int8 output, test_config5_*)
-            q4, _ = eq.forward(torch.from_numpy(O.quantize_input(x, net.scale[0], net.zero[0])).to(_dev()))
-            _cmp(f"{net.name} {N}x{H}x{W} budget {budget}: fused front, int8 input", q4, want["q_out"])
+            _cmp("y", y, want["y"])
+            # an already-quantised frame gives the same bytes (an upstream net's int8 output: test_config5_*)
+            q4, _ = et.forward(torch.from_numpy(O.quantize_input(x, net.scale[0], net.zero[0])).to(_dev()))
+            _cmp(f"{net.name} {N}x{H}x{W} budget {budget}: trio, int8 input", q4, want["q_out"])
 
 
 def test_trio_with_separate_residual_tensor_and_odd_zero_points():
@@ -705,7 +698,6 @@ def test_trio_with_separate_residual_tensor_and_odd_zero_points():
     net.zero[1], net.zero[2], net.zero[3], net.zero[4] = -120, -101, -128, -77
     e = sesrq.Engine(bundle_from_oracle(net), _dev(), wg_budget=2)
     assert "mfma-trio-merged" in e.layer_engines() and e.launch_plan() == [(0, 1), (1, 3), (4, 1)]
-    assert sesrq.Engine(e.bundle, _dev(), fuse_hidden=2).launch_plan() == e.launch_plan()      # zero[1] != -128: no fused front
     for (N, H, W) in [(1, 19, 70), (2, 33, 121)]:
         x = rand_frame((N, 3, H, W), H)
         want = O.forward(net, x)
@@ -755,13 +747,10 @@ def test_config2_full_frame_1080p_on_the_timed_kernels():
     q1, y1 = e.forward(torch.from_numpy(x).to(_dev()), want_q=True, want_f=True)
     assert _sha(q1.cpu().numpy()) == ref["out_q_sha256"] and _sha(q.cpu().numpy()) == ref["out_q_sha256"]
     assert _sha(y1.cpu().numpy()) == ref["out_f_sha256"]
-    e1 = sesrq.Engine(e.bundle, _dev(), fuse_hidden=2)
-    assert e1.layer_engines() == ["mfma-quad-hybrid"] * 4 + ["mfma-h5-general"]
     e2 = sesrq.Engine(e.bundle, _dev(), fuse_hidden=0)
     assert e2.layer_engines() == ["mfma-f5-hybrid", "mfma-h3-merged", "mfma-h3-merged", "mfma-h3-merged", "mfma-h5-general"]
-    for ee in (e1, e2):
-        q2, _ = ee.forward(torch.from_numpy(x).to(_dev()))
-        assert torch.equal(q, q2)
+    q2, _ = e2.forward(torch.from_numpy(x).to(_dev()))
+    assert torch.equal(q, q2)
 
 
 def test_config3_full_frame_nrdm3_540p():
@@ -769,7 +758,6 @@ def test_config3_full_frame_nrdm3_540p():
     reference calibration) 1x3x540x960, whole frame."""
     _full_frame_case("nrdm_3_qat.crop.npz", (1, 3, 540, 960), 3, ["mfma-f5-merged"] + ["mfma-trio-merged"] * 3 + ["mfma-h5p-general"])
     _full_frame_case("nrdm_3.crop.npz", (1, 3, 540, 960), 3, ["mfma-f5-merged"] + ["mfma-trio-merged"] * 3 + ["mfma-h5p-merged"])
-    _full_frame_case("nrdm_3.crop.npz", (1, 3, 540, 960), 3, ["mfma-quad-merged"] * 4 + ["mfma-h5p-merged"], fuse_hidden=2)
 
 
 def test_batch_larger_than_one_chip_round():
@@ -781,6 +769,49 @@ def test_batch_larger_than_one_chip_round():
     q, _ = e.forward(torch.from_numpy(x).to(_dev()))
     want = CO.forward(net, x, want_f=False)["q_out"]
     _cmp("72 x 36 x 1030", q, want)
+
+
+def test_forward_many_gives_sesrq_forward_bytes():
+    """sesrq_forward_many (round 4): many independent frames, distinct caller buffers, several streams, ONE call -- per frame the bytes
+    of sesrq_forward; windows that start anywhere in the cycle, more frames than the list holds, fp32 and int8 frames, an fp32 output."""
+    net = O.synth_net("sesr_x4", 17)
+    b = bundle_from_oracle(net)
+    e = sesrq.Engine(b, _dev(), wg_budget=64)
+    S, F = 3, 6
+    xs = [torch.from_numpy(rand_frame((1, 1, 45, 130), 100 + k)).to(_dev()) for k in range(F)]
+    want = [e.forward(x) for x in xs]
+    streams = [torch.cuda.Stream(device=_dev()) for _ in range(S)]
+    outs = [torch.zeros_like(want[0][0]) for _ in range(F)]
+    outf = [torch.zeros_like(want[0][1]) for _ in range(F)]
+    torch.cuda.synchronize()
+    sub = e.submission(xs, outs, streams, outs_f=outf)
+    sub.enqueue(F)
+    torch.cuda.synchronize()
+    for k in range(F):
+        assert torch.equal(outs[k], want[k][0]) and torch.equal(outf[k], want[k][1]), k
+    # a window in the middle of the cycle, longer than the list: frames 4, 5, 0, 1, ..., each on ITS stream of the cycle
+    for o in outs:
+        o.zero_()
+    torch.cuda.synchronize()
+    sub.enqueue(2 * F + 1, first=4)
+    torch.cuda.synchronize()
+    for k in range(F):
+        assert torch.equal(outs[k], want[k][0]), k
+    # int8 frames (already q0), no fp32 output
+    q0 = [torch.from_numpy(O.quantize_input(x.cpu().numpy(), net.scale[0], net.zero[0])).to(_dev()) for x in xs]
+    outs8 = [torch.zeros_like(want[0][0]) for _ in range(F)]
+    e.submission(q0, outs8, streams).enqueue(F)
+    torch.cuda.synchronize()
+    for k in range(F):
+        assert torch.equal(outs8[k], want[k][0]), k
+    # errors: a bad frame is reported with its index
+    import ctypes as C
+    io = (_lib.FrameIO * 2)(_lib.FrameIO(xs[0].data_ptr(), outs[0].data_ptr(), None), _lib.FrameIO(xs[1].data_ptr(), None, None))
+    ws = e.workspace(1, 45, 130, 0)
+    rc = _lib.lib().sesrq_forward_many(e._h, io, 2, _lib.F32, 1, 45, 130, (C.c_void_p * 1)(ws.data_ptr()), ws.numel(),
+                                       (C.c_void_p * 1)(torch.cuda.current_stream().cuda_stream), 1)
+    assert rc != 0 and "frame 1" in _lib.last_error()
+    torch.cuda.synchronize()
 
 
 def test_side_stream_with_non_contiguous_input():

@@ -3,8 +3,8 @@
 # (hipcc -save-temps into .scratch/isa, then tools/isa_count.py)
 set -e
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
-mkdir -p $ROOT/.scratch/isa
-cd $ROOT/.scratch/isa
+mkdir -p /tmp/sesrq_isa
+cd /tmp/sesrq_isa
 STEM=$1; shift
 if [ ! -f $STEM-hip-amdgcn-amd-amdhsa-gfx950.s ] || [ $ROOT/sesr-pytorch-quantize_amd/csrc/$STEM.hip -nt $STEM-hip-amdgcn-amd-amdhsa-gfx950.s ] || [ $ROOT/sesr-pytorch-quantize_amd/csrc/sesrq_mfma_common.h -nt $STEM-hip-amdgcn-amd-amdhsa-gfx950.s ] || [ $ROOT/sesr-pytorch-quantize_amd/csrc/sesrq_common.h -nt $STEM-hip-amdgcn-amd-amdhsa-gfx950.s ]; then
   /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -fno-fast-math -mllvm -amdgpu-mfma-vgpr-form $ISA_FLAGS \
