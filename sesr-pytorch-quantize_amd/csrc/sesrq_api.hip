@@ -99,7 +99,7 @@ static void pack_mfma_frags(const sesrq_layer_desc &d, int kind, bool general, i
     int F = 0;
     switch (kind) {
         case MFMA_H3: F = general ? 4 : 3; break;
-        case MFMA_H5: F = general ? 8 : 7; break;
+        case MFMA_H5: F = general ? 16 : 7; break;      // general: two sets of 8, one per row parity (h5_pair, sesrq_common.h)
         case MFMA_F5: F = general ? 8 : 2; break;
         case MFMA_H5P: F = 7; break;
     }
@@ -125,10 +125,10 @@ static void pack_mfma_frags(const sesrq_layer_desc &d, int kind, bool general, i
                     else if (f == 5) { ky = g; kx = 4; }
                     else if (g == 0) { ky = 4; kx = 4; }
                 } else if (kind == MFMA_H5) {
-                    // per PE p two K-chunks of two vertical pixel pairs per lane group: dword i = pair i / 2, element i % 2 (h5_tap)
-                    const int fi = f >> 2, p = f & 3;
+                    // per row parity and PE p two K-chunks of two vertical pixel pairs per lane group: dword i = pair i / 2, element i % 2 (h5_tap)
+                    const int par = f >> 3, fi = (f >> 2) & 1, p = f & 3;
                     ch = p + 4 * j;
-                    if (!h5_tap(fi, g, i >> 1, i & 1, ky, kx)) ky = -1;
+                    if (!h5_tap(fi, g, i >> 1, i & 1, par, ky, kx)) ky = -1;
                 }
                 else if (kind == MFMA_H5P) {
                     ch = chmap16(b);

@@ -53,36 +53,36 @@ __host__ __device__ inline void f5_tr(int g, int &row, int &col) {
 }
 __host__ __device__ inline void f5_pt(int i, int &row, int &col) { row = i == 0 ? 0 : 1; col = i < 2 ? 0 : i - 1; }
 
-// 5x5 per-PE chains (MFMA_H5 general image; kernels: mfma_h5_kernel).  A lane's 16 operand bytes per PE and K-chunk are TWO
-// VERTICAL PAIRS of pixels: K-chunk c, lane group g, pair q covers the taps (ky = start, start + 1; kx = col) of
-// h5_pair(c, g, q).  In the column-major planar LDS image (sesrq_mfma.hip) a vertical pair is two adjacent dwords = one
-// ds_read2_b32 into two consecutive registers, and the two lane groups of a 32-lane half (the conflict domain of a dword read)
-// always sit an ODD number of rows apart, which with a column pitch of 2 mod 4 dwords puts them on disjoint banks.  15 pairs
-// cover the 25 taps (every column: start 0, start 3, and start 1 or 2); a tap covered twice carries its weight in the FIRST
-// pair of the order (c, q, g) only (h5_tap), the 16th pair is padding.
+// 5x5 per-PE chains (MFMA_H5 general image; kernels: mfma_h5_kernel).  A lane's 16 operand bytes per PE and K-chunk are TWO VERTICAL
+// PAIRS of pixels.  Round 4: every pair starts on an EVEN row of the tile, so that in the column-major planar LDS image
+// ([PE][col][row], column pitch even) a pair is ONE 8-byte-aligned LDS access: measured (tools/lds_unaligned_probe.hip) an aligned
+// ds_read_b64 costs 3.45 cycles of the CU's LDS pipe and a ds_read2_b64 (two aligned pairs) 8.1, the ds_read2_b32 that fetched ONE pair of
+// arbitrary alignment in round 3 costs 8.1 too, and a ds_read_b64 that is only dword-aligned 64.  An output row r of the tile reads tile
+// rows r .. r + 4; the three aligned pairs that cover them start at r - par + s, s in {0, 2, 4}, par = r & 1: an even row uses taps
+// ky = (0,1) (2,3) (4,-), an odd row (-,0) (1,2) (3,4).  The kernel therefore gives every wave rows of ONE parity (wave w: parity w & 1,
+// two 16-column groups) and the weight image holds one set of A fragments per parity (pack_mfma_frags); the pixel addresses are the same
+// for both parities.
+// h5_pair(c, g, q): K-chunk c, lane group g, pair q covers column `col`, tile rows r - par + start, + 1.  15 pairs cover the 25 taps (five
+// of them half empty), the 16th is padding.  K-chunk 0: the two pairs of a lane are vertically adjacent (4 consecutive rows of one
+// column: ONE 16-byte read of 8-byte alignment = ds_read2_b64 straight into the operand registers); K-chunk 1: two separate pairs.
+// Banks (8-byte accesses: 64 banks, two lane groups of 16 lanes per LDS cycle): with a column pitch of 4 mod 8 dwords the 16 lanes of a
+// group sit 4 banks apart, each takes two, and the other lane group of the same 32-lane half fills the gaps iff its pair starts 2 rows
+// (mod 4) away: true for K-chunk 0 (odd lane groups start 2 rows lower) and for the first pair of K-chunk 1; the second is two-way.
 __host__ __device__ inline void h5_pair(int c, int g, int q, int &col, int &start) {
     //                         g0      g1      g2      g3
-    const int tab[4][4][2] = {{{0, 0}, {0, 3}, {1, 0}, {1, 3}},      // chunk 0, pair 0
-                              {{2, 0}, {2, 3}, {3, 0}, {3, 3}},      // chunk 0, pair 1
-                              {{4, 0}, {4, 3}, {0, 2}, {1, 1}},      // chunk 1, pair 0
-                              {{2, 2}, {3, 1}, {4, 2}, {4, 1}}};     // chunk 1, pair 1  (g3: padding)
+    const int tab[4][4][2] = {{{0, 0}, {1, 2}, {2, 0}, {3, 2}},      // chunk 0, pair 0
+                              {{0, 2}, {1, 4}, {2, 2}, {3, 4}},      // chunk 0, pair 1 = pair 0 two rows down
+                              {{0, 4}, {4, 2}, {2, 4}, {4, 2}},      // chunk 1, pair 0  (g3: padding, reads a pair that carries no weight)
+                              {{1, 0}, {4, 4}, {3, 0}, {4, 0}}};     // chunk 1, pair 1
     col = tab[c * 2 + q][g][0];
     start = tab[c * 2 + q][g][1];
 }
-// tap of element e (0, 1) of that pair, or false if the tap already belongs to an earlier pair / the pair is padding
-__host__ __device__ inline bool h5_tap(int c, int g, int q, int e, int &ky, int &kx) {
+// tap of element e (0, 1) of that pair for output rows of parity par, or false if the element is padding
+__host__ __device__ inline bool h5_tap(int c, int g, int q, int e, int par, int &ky, int &kx) {
     int col, start;
     h5_pair(c, g, q, col, start);
-    ky = start + e; kx = col;
-    for (int cc = 0; cc < 2; ++cc)
-        for (int qq = 0; qq < 2; ++qq)
-            for (int gg = 0; gg < 4; ++gg) {
-                if (cc == c && qq == q && gg == g) return !(c == 1 && q == 1 && g == 3);
-                int c2, s2;
-                h5_pair(cc, gg, qq, c2, s2);
-                if (c2 == col && (s2 == ky || s2 + 1 == ky)) return false;
-            }
-    return false;
+    ky = start + e - par; kx = col;
+    return !(c == 1 && q == 0 && g == 3) && ky >= 0 && ky <= 4;
 }
 
 // Last layer on the MFMA engine (mfma_h5_kernel<.., EPI_LAST>): which output channel sits in accumulator row 4g + i, i.e. in

@@ -197,12 +197,27 @@ struct LastStore {
 //   PW  > 0: PE-planar image for the per-PE (general) kernels: row pitch 4*PW dwords, dword [row][p][col] = word p
 //            (the 4 channels of PE p) of the pixel -- a lane's MFMA operand (4 pixels of ONE PE) is then read
 //            directly by dword loads with immediate plane offsets, no register shuffling.
-//   CP  > 0: column-major PE-planar image (5x5 per-PE kernel): dword [col][p][row], plane pitch CP >= SH, column pitch 4*CP + 2
-//            -- vertical neighbours are 1 dword apart, horizontal ones 4*CP + 2, the four planes CP: every operand dword of every
-//            row of a tile is within the 8-bit dword offsets of ds_read2_b32 from ONE lane-constant address.
-template <int SH, int SW, int R, int PW = 0, int CP = 0>
+//   CP  > 0: column-major PE-planar image (5x5 per-PE kernel): dword [p][col][row], column pitch CSP >= SH, plane pitch CP >= SW * CSP
+//            -- vertical neighbours are 1 dword apart, horizontal ones CSP, the four planes CP: every operand of every row of a tile
+//            is an immediate offset away from ONE lane-constant address.
+template <int SH, int SW, int R, int PW = 0, int CP = 0, int CSP = 0>
 struct StageNHWC16 {
     static constexpr int NIT = (SH * SW + 255) / 256;
+    // element i of the window -> (row, column).  Row-major for the pixel-major images.  Column-major planar image (CP > 0): blocks of 8
+    // columns x 4 rows per 32 lanes -- a dword store's 32 lanes then hit 32 different banks of the column-major image (column pitch 12:
+    // 8 columns = 8 multiples of 4, + 4 rows), where 32 consecutive columns of one row hit 8 (4-way conflicts: measured, 6.3 M conflict
+    // cycles per 1080p frame together with the reads' share); 8 lanes still load one whole 128-byte line
+    __device__ __forceinline__ static void rc_of(int i, int &row, int &col) {
+        if constexpr (CP > 0) {
+            static_assert(CP == 0 || (SW % 8 == 0 && SH % 4 == 0), "8 x 4 staging blocks");
+            const int u = i >> 5;
+            row = (u / (SW / 8)) * 4 + ((i >> 3) & 3);
+            col = (u % (SW / 8)) * 8 + (i & 7);
+        } else {
+            row = i / SW;
+            col = i - row * SW;
+        }
+    }
     v4u v[NIT];
     bool ok[NIT];
     bool interior;               // wave-uniform: every staged pixel of the tile lies inside the frame -> no pad selects in store()
@@ -222,8 +237,9 @@ struct StageNHWC16 {
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
             const int i = tid + it * 256;
-            ty[it] = i / SW;
-            const int tx = i - ty[it] * SW, gx = x0 - R + tx;
+            int tx;
+            rc_of(i, ty[it], tx);
+            const int gx = x0 - R + tx;
             const bool okx = (gx >= 0) & (gx < a.W) & (i < SH * SW);
             voff[it] = okx ? (ty[it] * a.W + gx) * 16 : (int)0x80000000;
             if (!okx) ty[it] = -(1 << 20);       // never a valid row -> pad
@@ -265,9 +281,10 @@ struct StageNHWC16 {
             const v4u t = (!PADSEL || ok[it]) ? v[it] : pad;
             if constexpr (CP > 0) {
                 int *tw = reinterpret_cast<int *>(tile);
-                const int row = i / SW, col = i - row * SW;
+                int row, col;
+                rc_of(i, row, col);
                 if (i < SH * SW) {
-                    int *d = tw + col * (4 * CP + 2) + row;
+                    int *d = tw + col * CSP + row;
                     d[0] = (int)t[0]; d[CP] = (int)t[1]; d[2 * CP] = (int)t[2]; d[3 * CP] = (int)t[3];
                 }
             } else if constexpr (PW == 0) {
@@ -435,17 +452,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void m
     constexpr bool GENERAL = mode_general(MODE);
     constexpr int SW = MTW + 8;          // 2 + 64 + 2 halo, + over-read of the kx = 4..7 group
     constexpr int SH = MTH + 4;
-    // per-PE (general) kernels: column-major PE-planar image [col][PE][row] (StageNHWC16, CP > 0): plane pitch CP = 13 dwords,
-    // column pitch CS = 54.  A lane's operand per PE and K-chunk = two vertical pixel pairs (h5_pair, sesrq_common.h) = two
-    // ds_read2_b32 of adjacent dwords straight into the four operand registers; all 4 PEs x 8 rows of a tile are reached by
-    // immediate offsets from four lane-constant addresses (one per chunk and pair): no address arithmetic and no operand moves
-    // in the row loop (round 2: [row][PE][col] with a 312-dword row pitch -- 7 address VALU + 6 v_mov per row, because vertically
-    // adjacent pixels were out of ds_read2_b32's offset range).  Banks: the 16 lanes of a group are 54 dwords apart = 16
-    // distinct EVEN banks (22 n mod 32), the two lane groups of a 32-lane half are an odd number of rows apart (h5_pair) = the
-    // odd banks: no conflicts.
-    constexpr int CP = GENERAL ? SH + 1 : 0;
-    constexpr int CS = 4 * CP + 2;
-    __shared__ int4 buf0[GENERAL ? (SW * CS + 3) / 4 : SH * SW], buf1[GENERAL ? (SW * CS + 3) / 4 : SH * SW];
+    // per-PE (general) kernels: column-major PE-planar image [PE][col][row] (StageNHWC16, CP > 0), column pitch CS = 12 dwords (the tile's
+    // rows), plane pitch CP = 72 columns.  A lane's operand per PE and K-chunk = two vertical pixel pairs that start on EVEN tile rows
+    // (h5_pair, sesrq_common.h): 8-byte-aligned LDS accesses straight into the four operand registers -- K-chunk 0 one ds_read2_b64 of four
+    // consecutive rows, K-chunk 1 two ds_read_b64 (round 3: four ds_read2_b32 of pairs of any alignment, 1.75 x the LDS cycles).  That needs
+    // output rows of one parity per wave: wave w works on rows (w & 1) + 2t, t = 0..3, of TWO 16-column groups (w >> 1), with the A
+    // fragments of its parity.  All 4 PEs x 4 rows of a column group are reached by immediate offsets from three lane-constant addresses;
+    // the planes are more than a ds_read2_b64's offset range apart, so hipcc cannot pair reads of different PEs (it did, and then moved
+    // 192 registers per tile into operand order).  Banks: h5_pair; the staging writes (dword stores 12 apart) are 4-way.
+    constexpr int CS = GENERAL ? SH : 0;
+    constexpr int CP = SW * CS;
+    static_assert(!GENERAL || (CS % 8 == 4 && CP * 4 > 2040), "aligned pairs / bank rule / no ds_read2 across PE planes");
+    constexpr int SHB = SH + (MODE == HYB ? 1 : 0);      // hybrid: the risky PE's pairs reach one row below the tile (zero weights)
+    __shared__ int4 buf0[GENERAL ? CP : SHB * SW], buf1[GENERAL ? CP : SHB * SW];      // general: 4 planes of CP dwords
     const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, n = l & 15, g = l >> 4;
     const int x0 = blockIdx.x * MTW, n_img = blockIdx.z;
     const int4 *fr = a.afrag;
@@ -455,34 +474,43 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void m
     const float zlo = a.relu ? fmaxf(EPI == EPI_LAST ? a.z_out : a.z_next, -128.f) : -128.f;
     const int gx = x0 + 16 * w + n;
     // merged: K-chunks 0..4 = kernel row f, lane group g = kx 0..3;  5 = column 4, lane group g = ky 0..3;  6 = tap (4,4)
-    // general, per PE p two K-chunks of two vertical pixel pairs per lane group (h5_pair; pack_mfma_frags, MFMA_H5)
+    // general, per PE p two K-chunks of two vertical pixel pairs per lane group (h5_pair; pack_mfma_frags, MFMA_H5), one set per row parity
     constexpr int NF = GENERAL ? 8 : 7;
+    // general: this wave's row parity and pair of 16-column groups -- wave-uniform, and TOLD so (readfirstlane): everything derived from
+    // them (row offsets of the stores, column bases) is then scalar arithmetic instead of VALU + v_readfirstlane per row
+    const int wu = __builtin_amdgcn_readfirstlane(w);
+    const int par = GENERAL ? (wu & 1) : 0, cg = wu >> 1;
     v4i A[NF];
 #pragma unroll
-    for (int f = 0; f < NF; ++f) A[f] = ld_frag(fr + 4 + f * 64 + l);
+    for (int f = 0; f < NF; ++f) A[f] = ld_frag(fr + 4 + (par * 8 + f) * 64 + l);
     // per-PE chains (general, and the risky PE's chain of the hybrid mode); must match pack_mfma_frags (MFMA_H5 general)
     int pcol[2][2], prow[2][2];                         // [chunk][pair]: column and first row of lane group g's pixel pair
 #pragma unroll
     for (int c = 0; c < 2; ++c)
 #pragma unroll
         for (int q = 0; q < 2; ++q) h5_pair(c, g, q, pcol[c][q], prow[c][q]);
-    LastStore ls;
-    if constexpr (EPI == EPI_LAST) ls.template init<NV>(a, n_img, g, gx);
+    LastStore ls, ls1;                                  // general: one per column group of the wave
+    if constexpr (EPI == EPI_LAST) {
+        if constexpr (GENERAL) { ls.template init<NV>(a, n_img, g, x0 + 32 * cg + n); ls1.template init<NV>(a, n_img, g, x0 + 32 * cg + 16 + n); }
+        else ls.template init<NV>(a, n_img, g, gx);
+    }
     v4i AR[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
     if constexpr (MODE == HYB) {
         AR[0] = ld_frag(a.afrag2 + 4 + (0 * 4 + a.risky_pe) * 64 + l);
         AR[1] = ld_frag(a.afrag2 + 4 + (1 * 4 + a.risky_pe) * 64 + l);
     }
-    // lane-constant byte offsets of the four pixel pairs inside a tile, computed ONCE (pinned: hipcc re-derived them -- 8 v_mul_lo
-    // + a dozen adds -- at the top of every tile)
-    unsigned pboff[2][2];
+    // lane-constant byte offsets of the four pixel pairs inside a tile for both column groups, computed ONCE (pinned: hipcc re-derived them
+    // -- 8 v_mul_lo + a dozen adds -- at the top of every tile)
+    unsigned pboff[2][2][2];
 #pragma unroll
-    for (int c = 0; c < 2; ++c)
+    for (int j = 0; j < 2; ++j)
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            pboff[c][q] = GENERAL ? (unsigned)(((16 * w + n + pcol[c][q]) * CS + prow[c][q]) * 4) : 0u;
-            asm volatile("" : "+v"(pboff[c][q]));
-        }
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                pboff[j][c][q] = GENERAL ? (unsigned)(((32 * cg + 16 * j + n + pcol[c][q]) * CS + prow[c][q]) * 4) : 0u;      // [0][1] unused: pair 1 of K-chunk 0 = pair 0 + 2 rows
+                asm volatile("" : "+v"(pboff[j][c][q]));
+            }
     auto compute = [&](const int4 *tile, int y0) __attribute__((always_inline)) {
         RowIO io;
         if constexpr (EPI != EPI_LAST) io = make_rowio(a, n_img, y0, gx, g);
@@ -531,50 +559,58 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void m
                 if constexpr (EPI != EPI_LAST) emit_rows4<EPI, false, BIASED>(s4, a, io, y4, zlo);
             }
         } else {
-            typedef int v2iu __attribute__((ext_vector_type(2), aligned(4)));      // two adjacent dwords, dword-aligned: ds_read2_b32
-            typedef const v2iu __attribute__((address_space(3))) *lds_pair_t;
+            typedef int v2ia __attribute__((ext_vector_type(2)));                  // two adjacent dwords, 8-byte aligned: ds_read_b64
+            typedef const v2ia __attribute__((address_space(3))) *lds_pair_t;
             const unsigned tb = (unsigned)(size_t)(const __attribute__((address_space(3))) void *)tile;     // LDS byte address of the tile
-            unsigned pb[2][2];                                          // [chunk][pair]: LDS byte address of the pair's first pixel, row 0, PE 0
 #pragma unroll
-            for (int c = 0; c < 2; ++c)
-#pragma unroll
-                for (int q = 0; q < 2; ++q) pb[c][q] = tb + pboff[c][q];
-#pragma unroll
-            for (int y4 = 0; y4 < MTH; y4 += 4) {
+            for (int j = 0; j < 2; ++j) {                                // the wave's two 16-column groups
+                const int gxj = x0 + 32 * cg + 16 * j + n;
+                // LDS byte addresses (row 0, PE 0) of the four pairs.  K-chunk 0's second pair is the first one two rows down, but it gets an
+                // address register of its own: reads off ONE register 8 bytes apart become a ds_read2_b64, which the LDS serves 16 lanes at a
+                // time over 32 banks (column pitch 12: two-way conflicts, half the rate) where a ds_read_b64 goes 32 lanes at a time over 64
+                unsigned pa0 = tb + pboff[j][0][0], pa1 = tb + pboff[j][0][0] + 8, p0 = tb + pboff[j][1][0], p1 = tb + pboff[j][1][1];
                 int s4[4][4];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int y = y4 + r;
+                for (int t = 0; t < 4; ++t) {                            // tile rows par + 2t
+                    const int gy = y0 + par + 2 * t;
                     const v4i zero = {0, 0, 0, 0};
                     v4i acc[4];
-                    // the pair of row y + 1 overlaps the pair of row y by one dword: hide the relation between the rows' addresses
-                    // from the compiler, which otherwise loads the shared dword once and then MOVES it into place (8 v_mov per row
-                    // and 168 VGPRs; the reads are not what bounds this loop, vector issue is)
-                    asm("" : "+v"(pb[0][0]), "+v"(pb[0][1]), "+v"(pb[1][0]), "+v"(pb[1][1]));
+                    // a pair of row t + 1 is a pair of row t in another operand slot: hide the relation between the rows' addresses from the
+                    // compiler, which otherwise keeps the pair and MOVES it into place (the reads are not what bounds this loop, vector issue is)
+                    asm("" : "+v"(pa0), "+v"(pa1), "+v"(p0), "+v"(p1));
+                    v4i b0[4], b1[4];
 #pragma unroll
                     for (int p = 0; p < 4; ++p) {
-                        const int o = y4 + (r + p * CP);
-                        const v2iu a0 = *(lds_pair_t)(size_t)(pb[0][0] + 4 * o), a1 = *(lds_pair_t)(size_t)(pb[0][1] + 4 * o);
-                        const v2iu c0 = *(lds_pair_t)(size_t)(pb[1][0] + 4 * o), c1 = *(lds_pair_t)(size_t)(pb[1][1] + 4 * o);
-                        const v4i b0 = {a0[0], a0[1], a1[0], a1[1]};
-                        const v4i b1 = {c0[0], c0[1], c1[0], c1[1]};
-                        acc[p] = mfma(A[p], b0, zero);
-                        acc[p] = mfma(A[4 + p], b1, acc[p]);
+                        const int o = 4 * (2 * t + p * CP);
+                        const v2ia a0 = *(lds_pair_t)(size_t)(pa0 + o), a1 = *(lds_pair_t)(size_t)(pa1 + o);
+                        const v2ia c0 = *(lds_pair_t)(size_t)(p0 + o), c1 = *(lds_pair_t)(size_t)(p1 + o);
+                        b0[p] = (v4i){a0[0], a0[1], a1[0], a1[1]};
+                        b1[p] = (v4i){c0[0], c0[1], c1[0], c1[1]};
                     }
-                    if constexpr (MODE == GEN_TAP) tap_sums<NV>(acc, a, n_img, y0 + y, gx, g, EPI == EPI_LAST ? NV : 0);
-                    finish_sums<MODE, NV>(s4[r], acc, ac, a);
+#pragma unroll
+                    for (int p = 0; p < 4; ++p) {
+                        acc[p] = mfma(A[p], b0[p], zero);
+                        acc[p] = mfma(A[4 + p], b1[p], acc[p]);
+                    }
+                    if constexpr (MODE == GEN_TAP) tap_sums<NV>(acc, a, n_img, gy, gxj, g, EPI == EPI_LAST ? NV : 0);
+                    finish_sums<MODE, NV>(s4[t], acc, ac, a);
                     if constexpr (EPI == EPI_LAST) {
-                        // a row below the frame is dropped by its offsets (FAST: the scalar one, else the lanes'), not by a
-                        // branch: the four rows stay one basic block
-                        ls.template store<BIASED, FAST, NV>(s4[r], a, y0 + y, zlo, y0 + y < a.H);
+                        // a row below the frame is dropped by its offsets (FAST: the scalar one, else the lanes'), not by a branch
+                        if (j == 0) ls.template store<BIASED, FAST, NV>(s4[t], a, gy, zlo, gy < a.H);
+                        else ls1.template store<BIASED, FAST, NV>(s4[t], a, gy, zlo, gy < a.H);
                     }
                 }
-                if constexpr (EPI != EPI_LAST) emit_rows4<EPI, false, BIASED>(s4, a, io, y4, zlo);
+                if constexpr (EPI != EPI_LAST) {
+                    // hidden 5x5 layer: the wave's four rows are two apart: lane (n, r' = g) stores pixel row y0 + par + 2g
+                    RowIO ioj = make_rowio(a, n_img, y0, gxj, g);
+                    ioj.voff = (gxj < a.W) ? ((y0 + par + 2 * g) * a.W + gxj) * 16 : (int)0x80000000;
+                    emit_rows4<EPI, false, BIASED>(s4, a, ioj, 0, zlo);
+                }
             }
         }
     };
 #define SESRQ_COMPUTE(B) compute(B, y0);
-    using Stage = StageNHWC16<SH, SW, 2, 0, CP>;
+    using Stage = StageNHWC16<SH, SW, 2, 0, CP, CS>;
     SESRQ_TILE_WALK(Stage, buf0, buf1, SESRQ_COMPUTE)
 #undef SESRQ_COMPUTE
 }
@@ -685,7 +721,7 @@ struct StageFrame {
     __amdgpu_buffer_rsrc_t rs, rsp[ZPAD ? (NCH < 4 ? NCH : 4) : 1];
     int row_bytes, plane_bytes;
     InQuantV qc;
-    __device__ __forceinline__ static float pin(float x) { float r; asm volatile("s_nop 1\n\tv_mov_b32 %0, %1" : "=v"(r) : "s"(x)); return r; }
+    __device__ __forceinline__ static float pin(float x) { float r = x; asm volatile("" : "+v"(r)); return r; }      // see in_vgpr()
     __device__ __forceinline__ void init(const ConvArgs &a, int n_img, int x0, int tid) {
         const size_t HW = (size_t)a.H * a.W;
         const size_t img = HW * a.ic * ESZ;

@@ -59,27 +59,29 @@ __device__ __forceinline__ unsigned quantize_in_bits(float x, const InQuantV &c)
     return __builtin_bit_cast(unsigned, __fadd_rn(__fadd_rn(q1, c.z), c.magic));
 }
 
-// A wave-uniform float pinned to a VGPR.  hipcc 7.2 (clang 22) un-packs a v_pk_fma_f32 that sits in the shadow of an MFMA into two
-// v_fma_f32; when the packed form read BOTH scalar operands out of one SGPR pair (s[n:n+1] with op_sel: 2^-n and the zero point
-// happen to be neighbours in the kernel arguments) the two halves become fma(v, s[n], s[n+1]) -- two scalar operands, illegal on
-// gfx9 ("VOP* instruction violates constant bus restriction", caught by the assembler printer, so a build error, never silent).
-// The requant's additive constant therefore travels in a VGPR wherever the register allocation made that pairing.
-// The s_nop is part of the contract of writing a VGPR from inline asm: hipcc pads hazards only for instructions it models, and it
-// placed this v_mov directly behind a buffer_store_dwordx4 whose first data register it re-used as the destination -- the store
-// then read the overwritten register ("VMEM store of more than 64 bits -> write of its data VGPRs" needs 2 wait states): word 0 of
-// some stored pixels was garbage, different from run to run (found by the 4K-frame test on the general first-layer kernel; the
-// same signature as round 2's "waves_per_eu(4) miscompile" of that kernel, whose first output word was garbage in some lanes).
+// A wave-uniform float pinned to a VGPR.  Why a VGPR: (1) hipcc 7.2 (clang 22) un-packs a v_pk_fma_f32 that sits in the shadow of an MFMA
+// into two v_fma_f32; when the packed form read BOTH scalar operands out of one SGPR pair the halves become fma(v, s[n], s[n+1]) -- two
+// scalar operands, illegal on gfx9 (a build error, never silent); (2) a scalar-operand v_fma / v_mul costs 2.2 ns per wave, the all-VGPR
+// form 1.45 (tools/op_cost_probe.hip).
+// How (round 4): the copy is the COMPILER's v_mov_b32; the asm statement is empty and only makes the value opaque.  Rounds 2-3 wrote the
+// v_mov inside the asm string ("s_nop 1; v_mov_b32 %0, %1"): hipcc models no hazard of an instruction it cannot see, and in round 4's
+// last-layer kernel the register allocator gave such a v_mov the dead fourth register of an MFMA result that was still in flight (the
+// padding row of the 12-channel layer) -- three instructions later the MFMA wrote its result over the constant (XDL write -> VALU write of
+// the same VGPR needs ~11 wait states): 9.5 M wrong bytes per 4K frame in the int8-only instance, found by bench.py's whole-frame parity.
+// The same class as round 3's store-data hazard (a v_mov directly behind a buffer_store_dwordx4 of that register); both are gone by
+// construction now: no VALU instruction of the kernels is hidden from the hazard recognizer except the SDWA adds of the residual merge,
+// whose operands are live VALU results (tools/store_hazard_scan.py checks what remains).
 __device__ __forceinline__ float in_vgpr(float x) {
-    float r;
-    asm("s_nop 1\n\tv_mov_b32 %0, %1" : "=v"(r) : "s"(x));
+    float r = x;
+    asm("" : "+v"(r));
     return r;
 }
 
 // 0x80808080 (u8 <-> two's complement, four bytes at once) as a VGPR operand: v_xor with a literal costs 2.0 ns per wave, with a
-// VGPR 1.4 (tools/op_cost_probe.hip); the asm is pure, so one v_mov per call site, hoisted out of the row loops
+// VGPR 1.4 (tools/op_cost_probe.hip); the statement is pure, so one v_mov per call site, hoisted out of the row loops
 __device__ __forceinline__ unsigned flip80(unsigned w) {
-    unsigned k;
-    asm("s_nop 1\n\tv_mov_b32 %0, 0x80808080" : "=v"(k));
+    unsigned k = 0x80808080u;
+    asm("" : "+v"(k));
     return w ^ k;
 }
 

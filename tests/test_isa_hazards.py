@@ -46,3 +46,9 @@ def test_scanner_follows_branches_and_sees_asm_defined_operands(tmp_path):
     assert rc == 1 and "inline asm" in out, out
     rc, out = run("\t;;#ASMSTART\n\ts_nop 1\n\tv_mov_b32 v8, s2\n\t;;#ASMEND\n\tv_add_f32_e32 v9, v8, v8\n")
     assert rc == 0, out
+    # round 4's bug: the asm v_mov lands in a register the MFMA in flight still writes (its result there is dead)
+    mf = "\tv_mfma_i32_16x16x64_i8 v[104:107], v[30:33], v[108:111], v[104:107]\n"
+    rc, out = run(mf + "\tv_add3_u32 v58, v58, v89, v61\n\t;;#ASMSTART\n\ts_nop 1\n\tv_mov_b32 v107, s59\n\t;;#ASMEND\n")
+    assert rc == 1 and "WAW" in out, out
+    rc, out = run(mf + "\ts_nop 15\n\ts_nop 3\n\t;;#ASMSTART\n\tv_mov_b32 v107, s59\n\t;;#ASMEND\n")
+    assert rc == 0, out

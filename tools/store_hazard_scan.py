@@ -7,6 +7,8 @@ nothing at all around inline asm: 0.02 % of the stores then carry the overwritte
 A second rule covers what hipcc cannot see at all: a VGPR written INSIDE an inline-asm statement (;;#ASMSTART .. ;;#ASMEND) and read by an
 MFMA or a vector-memory instruction within the next few instructions -- hipcc pads hazards only for instructions it models, so such a
 consumer would need the padding inside the asm string (today every asm-defined VGPR of the kernels feeds VALU / LDS instructions only).
+A third rule: an inline-asm VALU write of a VGPR inside the destination of an MFMA issued at most 18 wait states earlier (the MFMA writes
+its result late: a register whose MFMA result is dead can be handed out again at once; round 4's in_vgpr() bug, sesrq_mfma_common.h).
 usage: store_hazard_scan.py file.s ['demangled substring']   (exit status 1 if a site is found)"""
 import re, subprocess, sys
 src = sys.argv[1]
@@ -27,11 +29,26 @@ def written(op, args):
     return w
 hits = 0
 # ---- rule 2: inline-asm VGPR definitions feeding an MFMA or VMEM instruction right behind the statement
+# ---- rule 3: an inline-asm VALU write of a VGPR that an MFMA issued shortly before still has to write (WAW: hipcc pads it only for
+# instructions it models; it happens when the MFMA's result in that register is dead, so the allocator hands the register out again)
 kern2, in_asm, fresh = None, False, {}        # fresh: register -> instructions left in which a modelled consumer would be a hazard
+pending = {}                                  # register -> wait states left until a recent MFMA has surely written it
 for n, l in enumerate(lines):
     m = re.match(r"^(_Z\w+):", l)
     if m:
-        kern2 = m.group(1); fresh = {}
+        kern2 = m.group(1); fresh = {}; pending = {}
+    u0 = l.strip()
+    if u0 and not u0.startswith((";", ".")) and not re.match(r"^[.\w]+:", u0):
+        op0 = u0.split()[0]; args0 = [a.strip().rstrip(",") for a in u0.split()[1:]]
+        if in_asm and op0.startswith("v_") and args0:
+            bad = regs(args0[0]) & set(pending)
+            if bad and (not pat or pat in subprocess.run(["c++filt", kern2 or ""], capture_output=True, text=True).stdout):
+                hits += 1
+                print(f"{kern2}\n  line {n + 1}: {u0}   <- inline asm writes {sorted(bad)} while an MFMA issued <= 18 wait states earlier still writes it (unmodelled WAW)")
+        step = int(args0[0]) + 1 if op0 == "s_nop" and args0 else 1
+        pending = {r: c - step for r, c in pending.items() if c > step}
+        if op0.startswith(("v_mfma", "v_smfmac")) and args0:
+            for r in regs(args0[0]): pending[r] = 18
     u = l.strip()
     if u.startswith(";;#ASMSTART"): in_asm = True; continue
     if u.startswith(";;#ASMEND"): in_asm = False; continue
