@@ -374,11 +374,16 @@ def main():
 
 
 def e2e_leg(torch, engines, pool, outs, B, frames=96, depth=3, int8_in=False):
-    """Host -> device -> host for `frames` steps: pinned host buffers, H2D on one stream, the kernels on a second, D2H on a
-    third, `depth` frames in flight; PCIe-bound by construction (SURVEY 8e asks for it to be reported separately).  The first
-    DMA out of / into a freshly pinned buffer is slow (6 vs 56 GB/s measured here), so every buffer is cycled twice before
-    the clock starts.  int8_in: the frames cross PCIe already quantised (q0 = clamp8(rint(x / s0 + z0)) formed on the host -- what
-    a camera pipeline with uint8 frames hands over): a quarter of the input bytes, the engine's int8 entry (SESRQ_I8)."""
+    """Host -> device -> host for `frames` steps through pinned host buffers, `depth` frames in flight; PCIe-bound by construction (SURVEY
+    8e asks for it to be reported separately; never `value`).  Round 4: ONE STREAM PER FRAME SLOT -- H2D, the kernels and D2H of a frame
+    are enqueued on the slot's stream in order, the overlap comes from the `depth` slots; no event crosses a stream.  Rounds 2-3 ran H2D /
+    kernels / D2H on three streams tied together by events per frame: with the SDMA engines carrying the copies (ROCm's default) every such
+    cross-queue dependency is resolved through the host's signal handler, and the loop ran at a third of the copies' own rate AND slowed
+    down pass after pass (tools/e2e_probe.py, profiles/r04_e2e_probe.txt: 1317 / 880 / 657 steps/s, int8 frames slower than fp32; the copies
+    alone: 2240 steps/s each way, 1920 both ways; HSA_ENABLE_SDMA=0: stable 885 / 1100; one stream per slot: 1120-1570 fp32, 1380-2090
+    int8, no decay).  The first DMA out of / into a freshly pinned buffer is slow (6 vs 56 GB/s measured here), so every buffer is cycled
+    twice before the clock starts.  int8_in: the frames cross PCIe already quantised (q0 = clamp8(rint(x / s0 + z0)) formed on the host --
+    what a camera pipeline with uint8 frames hands over): a quarter of the input bytes, the engine's int8 entry (SESRQ_I8)."""
     dev = pool[0].device
     if int8_in:
         b0 = engines[0].bundle
@@ -390,45 +395,35 @@ def e2e_leg(torch, engines, pool, outs, B, frames=96, depth=3, int8_in=False):
     douts = [[torch.empty(s, dtype=torch.int8, device=dev) for s in shapes] for _ in range(depth)]
     hout = [torch.empty(shapes[-1], dtype=torch.int8).pin_memory() for _ in range(depth)]
     din = [torch.empty(pool[0].shape, dtype=hin[0].dtype, device=dev) for _ in range(depth)]
-    s_in, s_k, s_out = (torch.cuda.Stream(device=dev) for _ in range(3))
-    ev_in = [torch.cuda.Event() for _ in range(depth)]
-    ev_k = [torch.cuda.Event() for _ in range(depth)]
-    ev_out = [torch.cuda.Event() for _ in range(depth)]
+    slot_streams = [torch.cuda.Stream(device=dev) for _ in range(depth)]
     torch.cuda.synchronize()
 
     def run(n):
         for i in range(n):
             b = i % depth
-            with torch.cuda.stream(s_in):
-                s_in.wait_event(ev_k[b])                 # the kernels that read din[b] `depth` steps ago are done
+            st = slot_streams[b]
+            with torch.cuda.stream(st):        # stream order: the slot's previous D2H is done before its buffers are written again
                 din[b].copy_(hin[b], non_blocking=True)
-                ev_in[b].record(s_in)
-            s_k.wait_event(ev_in[b])
-            s_k.wait_event(ev_out[b])                    # the D2H of douts[b] `depth` steps ago is done
-            cur = din[b]
-            for j, e in enumerate(engines):
-                e.forward(cur, want_q=True, want_f=False, out_q=douts[b][j], stream=s_k, slot=b, assume_ordered=True)
-                cur = douts[b][j]
-            ev_k[b].record(s_k)
-            with torch.cuda.stream(s_out):
-                s_out.wait_event(ev_k[b])
+                cur = din[b]
+                for j, e in enumerate(engines):
+                    e.forward(cur, want_q=True, want_f=False, out_q=douts[b][j], stream=st, slot=b, assume_ordered=True)
+                    cur = douts[b][j]
                 hout[b].copy_(cur, non_blocking=True)
-                ev_out[b].record(s_out)
         torch.cuda.synchronize()
     run(2 * depth)
     dts = []
-    for _ in range(3):          # the copies share the DMA / blit path with whatever else the box does: median of three passes
+    for _ in range(5):          # the copies share the DMA engines with whatever else the box does: median of five passes
         t0 = time.perf_counter()
         run(frames)
         dts.append(time.perf_counter() - t0)
-    dt = sorted(dts)[1]
+    dt = sorted(dts)[2]
     mb_in = hin[0].numel() * hin[0].element_size() / 1e6
     mb_out = hout[0].numel() / 1e6
     return {"value": round(frames * B / dt, 2), "unit": "frames/s", "bound": "pcie", "input_dtype": "i8" if int8_in else "f32",
             "h2d_MB_per_step": round(mb_in, 2), "d2h_MB_per_step": round(mb_out, 2),
             "pcie_GBps": round((mb_in + mb_out) * frames / dt / 1e3, 2),
             "passes_fps": [round(frames * B / t, 1) for t in dts],
-            "note": f"pinned host buffers, H2D / kernels / D2H on three streams, {depth} frames in flight, median of 3 passes of {frames} steps; never `value`"}
+            "note": f"pinned host buffers, one stream per frame slot (H2D, kernels, D2H in stream order), {depth} frames in flight, median of 5 passes of {frames} steps; never `value`"}
 
 
 if __name__ == "__main__":
