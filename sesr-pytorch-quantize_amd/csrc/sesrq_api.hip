@@ -4,6 +4,8 @@
 #include <string.h>
 
 #include <algorithm>
+#include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <memory>
 #include <mutex>
@@ -642,29 +644,46 @@ static int run_job(SubmitJob &j) {
     return 0;
 }
 class SubmitPool {
+    // A worker spins on its job slot for SPIN_US after finishing a job (the bench hands over a block of frames every ~1 ms: a condition
+    // variable's wake-up would add 20-50 us to every block), then sleeps on the condition variable until the next call.
+    static constexpr int SPIN_US = 2000;
     struct Worker {
         std::thread th;
         std::mutex mu;
         std::condition_variable cv;
-        SubmitJob *job = nullptr;
-        bool done = true, quit = false;
+        std::atomic<SubmitJob *> job{nullptr};
+        std::atomic<bool> done{true}, asleep{false};
+        bool quit = false;
     };
     std::vector<std::unique_ptr<Worker>> workers;
     std::mutex call_mu;      // one sesrq_forward_many at a time uses the pool (a second concurrent caller enqueues on its own thread)
     static void loop(Worker *w) {
         int dev = -1;
         for (;;) {
-            std::unique_lock<std::mutex> lk(w->mu);
-            w->cv.wait(lk, [&] { return w->job || w->quit; });
-            if (w->quit) return;
-            SubmitJob *j = w->job;
-            lk.unlock();
+            SubmitJob *j = nullptr;
+            const auto t0 = std::chrono::steady_clock::now();
+            while (!(j = w->job.load(std::memory_order_acquire))) {
+                if (std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(SPIN_US)) {
+                    std::unique_lock<std::mutex> lk(w->mu);
+                    w->asleep.store(true);
+                    w->cv.wait(lk, [&] { return w->job.load(std::memory_order_acquire) || w->quit; });
+                    w->asleep.store(false);
+                    if (w->quit) return;
+                } else {
+                    __builtin_ia32_pause();
+                }
+            }
             if (dev != j->net->device) { dev = j->net->device; (void)hipSetDevice(dev); }      // a fresh thread starts on device 0
             run_job(*j);
-            lk.lock();
-            w->job = nullptr; w->done = true;
-            lk.unlock();
-            w->cv.notify_all();
+            w->job.store(nullptr, std::memory_order_release);
+            w->done.store(true, std::memory_order_release);
+        }
+    }
+    void grow(size_t n) {
+        while (workers.size() < n) {
+            workers.emplace_back(new Worker());
+            Worker *w = workers.back().get();
+            w->th = std::thread(loop, w);
         }
     }
 public:
@@ -675,25 +694,26 @@ public:
             if (w->th.joinable()) w->th.join();
         }
     }
+    // the threads exist (and spin) before the first batch that needs them: creating a thread costs more than the batch
+    void ensure(size_t n) {
+        std::unique_lock<std::mutex> call(call_mu, std::try_to_lock);
+        if (call.owns_lock()) grow(n);
+    }
     // jobs[0] runs on the caller's thread, jobs[1..] on the workers; false = the pool is busy (caller falls back to one thread)
     bool run(std::vector<SubmitJob> &jobs) {
         std::unique_lock<std::mutex> call(call_mu, std::try_to_lock);
         if (!call.owns_lock()) return false;
-        while (workers.size() + 1 < jobs.size()) {
-            workers.emplace_back(new Worker());
-            Worker *w = workers.back().get();
-            w->th = std::thread(loop, w);
-        }
+        grow(jobs.size() - 1);
         for (size_t i = 1; i < jobs.size(); ++i) {
             Worker *w = workers[i - 1].get();
-            { std::lock_guard<std::mutex> lk(w->mu); w->job = &jobs[i]; w->done = false; }
-            w->cv.notify_all();
+            w->done.store(false, std::memory_order_relaxed);
+            w->job.store(&jobs[i], std::memory_order_release);
+            if (w->asleep.load()) { std::lock_guard<std::mutex> lk(w->mu); w->cv.notify_all(); }
         }
         run_job(jobs[0]);
         for (size_t i = 1; i < jobs.size(); ++i) {
             Worker *w = workers[i - 1].get();
-            std::unique_lock<std::mutex> lk(w->mu);
-            w->cv.wait(lk, [&] { return w->done; });
+            while (!w->done.load(std::memory_order_acquire)) __builtin_ia32_pause();
         }
         return true;
     }
@@ -713,6 +733,7 @@ int sesrq_forward_many(const sesrq_net *net, const sesrq_frame_io *frames, int c
     // stream gets at least two frames (fewer: waking a thread costs more than the launches it takes over)
     static const int threads_knob = env_knob("SESRQ_SUBMIT_THREADS", 1, 0, 1);
     std::vector<SubmitJob> jobs;
+    if (threads_knob && n_streams > 1) submit_pool().ensure((size_t)n_streams - 1);
     const bool pooled = threads_knob && n_streams > 1 && count >= 2 * n_streams;
     const int nj = pooled ? n_streams : 1;
     if (pooled) {
