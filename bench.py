@@ -46,7 +46,9 @@ WORKLOADS = {
 
 # Launch plan per workload: (streams, wg_budget), chosen by throughput in same-box A/Bs (tools/plan_ab.sh; profiles/README.md, round 3):
 # 1080p: 3 streams x 512 slots 14.5 k frames/s vs 2 streams x full chip 14.2 k; anything else: the round-2 plan.
-PLAN = {"sesr_x2_1080p": (3, 512), "nrdm_3_540p": (3, 512), "sesr_x4_540p": (3, 512), "nrdm6_sesrx2_540p": (3, 512)}      # same-box A/Bs, profiles/README.md
+# The budget is counted in workgroup slots PER COMPUTE UNIT (2 = half of the four a CU holds for these kernels) and scaled by the device's
+# CU count at run time: 2 x 256 = 512 on an MI355X (not a constant of this chip).
+PLAN = {"sesr_x2_1080p": (3, 2), "nrdm_3_540p": (3, 2), "sesr_x4_540p": (3, 2), "nrdm6_sesrx2_540p": (3, 2)}      # (streams, slots per CU): same-box A/Bs, profiles/README.md
 PLAN_DEFAULT = (2, 0)
 
 
@@ -119,8 +121,8 @@ def main():
                          "buffers, only the host's per-step cost changes.  auto = many for a single net without --graph, else step")
     ap.add_argument("--wg-budget", type=int, default=-1,
                     help="workgroup slots a launch may fill (sesrq_options.wg_budget; 0 = one full round of the chip).  -1 = the workload's "
-                         "tuned plan (PLAN): 512 of the 1024 slots for the single-frame workloads, so that kernels of three frames stay co-resident "
-                         "on every CU instead of meeting only at their tails")
+                         "tuned plan (PLAN): two slots per compute unit (512 of an MI355X's 1024) for the single-frame workloads, so that kernels of three "
+                         "frames stay co-resident on every CU instead of meeting only at their tails")
     ap.add_argument("--timing-iters", type=int, default=200, help="forwards of the per-launch HIP-event timing (roofline)")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend of the timing fence (nccl = RCCL; gloo + --share-gpu rehearses N > 1 on a 1-GPU box)")
@@ -132,11 +134,9 @@ def main():
 
     if args.repeats <= 0:
         args.repeats = max(5, -(-1500 // max(1, args.steps)))
-    plan_streams, plan_budget = PLAN.get(args.workload, PLAN_DEFAULT)
+    plan_streams, plan_slots_per_cu = PLAN.get(args.workload, PLAN_DEFAULT)
     if args.streams <= 0:
         args.streams = plan_streams
-    if args.wg_budget < 0:
-        args.wg_budget = plan_budget
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus > 1 and world == 1:
         # not launched by torchrun: start the ranks as children (before anything touches the GPU)
@@ -157,6 +157,8 @@ def main():
         local = local % torch.cuda.device_count()
     torch.cuda.set_device(local)
     dev = torch.device(f"cuda:{local}")
+    if args.wg_budget < 0:
+        args.wg_budget = plan_slots_per_cu * torch.cuda.get_device_properties(dev).multi_processor_count
     # RCCL ("nccl") on a multi-GPU node; only the timing fence uses it.  gloo reduces on the host.
     grp = Group(backend=args.dist_backend, device=dev if args.dist_backend == "nccl" else None)
 

@@ -219,6 +219,12 @@ class SesrqGraphModule(torch.fx.GraphModule):
         b = eng.bundle
         L = b.L
         if flags["INPUT_W_FLG"] or flags["OUTPUT_PE_W_FLG"] or flags["OUTPUT_PE_ADD_W_FLG"]:
+            if (flags["OUTPUT_PE_W_FLG"] or flags["OUTPUT_PE_ADD_W_FLG"]) and x.shape[0] != 1:
+                # the reference asserts batch == 1 where it dumps the PE tensors (quan_func.py:373: pe_outputK_P.pt is ONE frame's (OC, H, W));
+                # a tree with frame 0's PE sums next to all frames' activations would be silently inconsistent
+                raise ValueError("the PE dump flags (OUTPUT_PE_W_FLG / OUTPUT_PE_ADD_W_FLG) need batch 1 like the reference's "
+                                 "(quan_func.py:373); got a batch of %d frames" % x.shape[0])
+            # (with a dump flag on, every forward runs a second, debug forward on the per-PE kernels: sesrq_forward_debug)
             res = eng.forward_debug(x.float() if x.dtype != torch.int8 else x,
                                     pe=flags["OUTPUT_PE_W_FLG"] or flags["OUTPUT_PE_ADD_W_FLG"])
             r = b.pixel_shuffle
