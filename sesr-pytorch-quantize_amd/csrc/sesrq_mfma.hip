@@ -308,7 +308,7 @@ struct StageNHWC16 {
 #ifdef SESRQ_STAMPS
 #define STAMP(k)                                                                                    \
     if (a.dbg_pe && tid == 0) {                                                                     \
-        int *sp = a.dbg_pe + ((blockIdx.y * gridDim.x + blockIdx.x) * 16 + (k)) * 2;                \
+        int *sp = a.dbg_pe + ((bxy.y * gridDim.x + bxy.x) * 16 + (k)) * 2;                \
         sp[0] = (int)__builtin_amdgcn_s_memrealtime();                                              \
         sp[1] = (int)__builtin_amdgcn_s_memtime();                                                  \
     }
@@ -319,8 +319,8 @@ struct StageNHWC16 {
 #define SESRQ_TILE_WALK_H(TILE_H, STAGE_T, BUF0, BUF1, COMPUTE)                                              \
     {                                                                                               \
         const int row_tiles_ = (a.H + (TILE_H) - 1) / (TILE_H);      /* runs of (almost) equal length */      \
-        const int t_begin = (int)(((long long)blockIdx.y * row_tiles_) / gridDim.y);                \
-        const int t_end = (int)(((long long)(blockIdx.y + 1) * row_tiles_) / gridDim.y);            \
+        const int t_begin = (int)(((long long)bxy.y * row_tiles_) / gridDim.y);                \
+        const int t_end = (int)(((long long)(bxy.y + 1) * row_tiles_) / gridDim.y);            \
         STAGE_T st;                                                                                 \
         st.init(a, n_img, x0, tid);                                                                 \
         STAMP(0)                                                                                    \
@@ -346,8 +346,8 @@ struct StageNHWC16 {
 #define SESRQ_TILE_WALK_CARRY(TILE_H, STAGE_T, BUF0, BUF1, COMPUTE)                                          \
     {                                                                                               \
         const int row_tiles_ = (a.H + (TILE_H) - 1) / (TILE_H);                                      \
-        const int t_begin = (int)(((long long)blockIdx.y * row_tiles_) / gridDim.y);                \
-        const int t_end = (int)(((long long)(blockIdx.y + 1) * row_tiles_) / gridDim.y);            \
+        const int t_begin = (int)(((long long)bxy.y * row_tiles_) / gridDim.y);                \
+        const int t_end = (int)(((long long)(bxy.y + 1) * row_tiles_) / gridDim.y);            \
         STAGE_T st;                                                                                 \
         st.init(a, n_img, x0, tid);                                                                 \
         st.load_first(a, n_img, x0, t_begin * (TILE_H), tid);                                       \
@@ -372,7 +372,8 @@ __global__ __launch_bounds__(256) void mfma_h3_kernel(const ConvArgs a) {
     constexpr int PW = GENERAL ? SW : 0;             // planar image: row pitch 4*68 = 272 dwords = 16 mod 64 banks
     __shared__ int4 buf0[SH * SW], buf1[SH * SW];
     const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, n = l & 15, g = l >> 4;
-    const int x0 = blockIdx.x * MTW, n_img = blockIdx.z;
+    const BlockXY bxy = xcd_block();
+    const int x0 = bxy.x * MTW, n_img = blockIdx.z;
     const int4 *fr = a.afrag;
     constexpr bool BIASED = mode_biased(MODE);     // requant without v_cvt: sums carry + MAGIC_I (needs |s| < 2^22)
     int4 ac = fr[g];
@@ -466,7 +467,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void m
     constexpr int SHB = SH + (MODE == HYB ? 1 : 0);      // hybrid: the risky PE's pairs reach one row below the tile (zero weights)
     __shared__ int4 buf0[GENERAL ? CP : SHB * SW], buf1[GENERAL ? CP : SHB * SW];      // general: 4 planes of CP dwords
     const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, n = l & 15, g = l >> 4;
-    const int x0 = blockIdx.x * MTW, n_img = blockIdx.z;
+    const BlockXY bxy = xcd_block();
+    const int x0 = bxy.x * MTW, n_img = blockIdx.z;
     const int4 *fr = a.afrag;
     constexpr bool BIASED = mode_biased(MODE);     // requant without v_cvt: sums carry + MAGIC_I (needs |s| < 2^22)
     int4 ac = fr[g];
@@ -627,7 +629,8 @@ __global__ __launch_bounds__(256) void mfma_h5p_kernel(const ConvArgs a) {
     constexpr int SH = MTH + 4;
     __shared__ int4 buf0[SH * SW], buf1[SH * SW];
     const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, n = l & 15, g = l >> 4;
-    const int x0 = blockIdx.x * MTW, n_img = blockIdx.z;
+    const BlockXY bxy = xcd_block();
+    const int x0 = bxy.x * MTW, n_img = blockIdx.z;
     const int4 *fr = a.afrag;
     constexpr bool BIASED = mode_biased(MODE);
     int4 ac = fr[0];
@@ -833,7 +836,8 @@ __device__ __forceinline__ void mfma_f5_body(const ConvArgs &a, int4 *buf0, int4
     constexpr bool GENERAL = mode_general(MODE);
     constexpr int SH = F5_SH, SWP = F5_SWP, PITCH = F5_PITCH;
     const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, n = l & 15, g = l >> 4;
-    const int x0 = blockIdx.x * MTW, n_img = blockIdx.z;
+    const BlockXY bxy = xcd_block();
+    const int x0 = bxy.x * MTW, n_img = blockIdx.z;
     const int4 *fr = a.afrag;
     constexpr bool BIASED = mode_biased(MODE);     // requant without v_cvt: sums carry + MAGIC_I (needs |s| < 2^22)
     int4 ac = fr[g];

@@ -317,6 +317,27 @@ __device__ __forceinline__ void transpose4(unsigned w[4]) {
     t = __builtin_amdgcn_permlane16_swap(w[2], w[3], false, false); w[2] = t[0]; w[3] = t[1];
 }
 
+// XCD-aware block -> (strip, run) map (round 4).  The dispatcher deals consecutive workgroup ids round-robin over the chip's 8 XCDs (blocks
+// b and b + 8 share one, MI355X_MICROARCH.md), each with an L2 of its own: with the identity map the neighbours of a tile -- which read the
+// same 128-byte lines at its edges and re-read its halo -- sit on OTHER XCDs, and every such line comes out of the Infinity Cache / HBM once
+// per XCD.  Here XCD x gets the x-th contiguous eighth of the run-major tile order, so those reads hit the L2 the first one filled.
+// Measured (same box, FETCH_SIZE x 2 as tools/fetch_calib_probe.hip calibrates it for 4-byte and 16-byte lanes alike): first layer 50.8 ->
+// 25.8 MB fetched for its 24.9 MB fp32 frame -- a 64-pixel tile row is two 128-byte lines per channel plane and its halo touches two more --
+// and 16.8 -> 14.6 us; trio 43.0 -> 35.0 MB (33.2 MB of input), last layer 43.0 -> 34.8 MB, times unchanged (they are issue-bound).
+// Speed only: nothing depends on which XCD a block lands on.
+struct BlockXY { int x, y; };
+__device__ __forceinline__ BlockXY xcd_block() {
+    BlockXY b = {(int)blockIdx.x, (int)blockIdx.y};
+    const unsigned nx = gridDim.x, total = nx * gridDim.y, per = total >> 3;
+    const unsigned id = blockIdx.y * nx + blockIdx.x;
+    if (id < per * 8) {      // the last total % 8 blocks keep their place
+        const unsigned v = (id & 7) * per + (id >> 3);
+        b.y = (int)(v / nx);
+        b.x = (int)(v - (unsigned)b.y * nx);
+    }
+    return b;
+}
+
 // Per-image NHWC16 tensor addressed through a buffer descriptor: rows/pixels outside the
 // frame are dropped (stores) or read as zero (loads) by the hardware range check.
 struct RowIO {

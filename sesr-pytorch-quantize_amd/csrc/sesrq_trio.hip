@@ -109,16 +109,17 @@ __global__ __launch_bounds__(256) void mfma_trio_kernel(const TrioArgs a) {
     // MAGIC + 256 + the table's LDS byte address (exact: < 2^24); see epi_preres_lut
     const float lut_magic = MAGIC + 256.f + (float)(unsigned)(size_t)(const __attribute__((address_space(3))) void *)lutp;
     const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, n = l & 15, g = l >> 4;
+    const BlockXY bxy = xcd_block();
     const int n_img = blockIdx.z;
-    const int x0 = blockIdx.x * TV - 2;              // frame column of computed column 0
+    const int x0 = bxy.x * TV - 2;              // frame column of computed column 0
     // vertical runs of (almost) equal length: run c of n covers units [c*U/n, (c+1)*U/n) of a.run_unit rows -- whole steps (8), or
     // half steps (4) where the runs are short (the launch decides): such a run is walked in full steps plus, for an odd count,
     // one closing half step.  A 540p frame on a full chip has 1 - 2 steps per run: 8- and 16-row runs became 8- and 12-row
     // runs, 18.8 -> 14.8 us.  Long runs (1080p: 4 - 5 steps) gain nothing from it -- the workgroups that finish early leave
     // their issue slots to the others -- and a half step costs more than half a step, so they stay on whole steps.
     const int units_total = (a.H + a.run_unit - 1) / a.run_unit;
-    const int y_begin = a.run_unit * (int)(((long long)blockIdx.y * units_total) / gridDim.y);
-    const int y_end = a.run_unit * (int)(((long long)(blockIdx.y + 1) * units_total) / gridDim.y);
+    const int y_begin = a.run_unit * (int)(((long long)bxy.y * units_total) / gridDim.y);
+    const int y_end = a.run_unit * (int)(((long long)(bxy.y + 1) * units_total) / gridDim.y);
     if (y_begin >= y_end) return;
     if constexpr (LUT) {           // visible to every wave long before the first residual merge (barriers of the cold start)
         if (threadIdx.x < 128) reinterpret_cast<int *>(lutp)[threadIdx.x] = a.merge_lut[threadIdx.x];

@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """Merge the rocprofv3 PMC passes of tools/profile_round.sh into <dir>/pmc_summary.json (bench.py reads the committed copy,
 profiles/pmc_summary.json) and a markdown table <dir>/sq_counters.md.  Per-launch averages over the bench kernels.
-HBM bytes per launch = 2 x FETCH_SIZE + WRITE_SIZE (KiB -> bytes): FETCH_SIZE reports half of the bytes of 16-B/lane streaming
-reads on gfx950, WRITE_SIZE is exact for 16-B/lane stores (/opt/skills/guides/MI355X_MICROARCH.md, HBM); narrower stores
+HBM bytes per launch = 2 x FETCH_SIZE + WRITE_SIZE (KiB -> bytes): FETCH_SIZE reports half of the bytes of coalesced streaming
+reads on gfx950 (4 and 16 B/lane calibrated), WRITE_SIZE is exact for 16-B/lane stores (/opt/skills/guides/MI355X_MICROARCH.md, HBM); narrower stores
 (the 2-byte PixelShuffle runs of the last layer) are uncalibrated and flagged."""
 import collections
 import csv
@@ -37,11 +37,11 @@ for li, k in enumerate(kernels):
     cyc = c.get("SQ_BUSY_CYCLES", 0) / N_SE                      # kernel length in cycles (SQ busy, per SE)
     ent = {"kernel": k.split("(")[0]}
     if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
-        # the x2 correction holds for 16-B/lane streaming reads (NHWC16 activations: trio, h3, h5 kernels); the first layer
-        # reads the fp32 planes one dword per lane -- uncalibrated in the guide; counted as reported (1.1 x its input bytes)
-        wide = "mfma_f5" not in k
-        ent["fetch_bytes"] = (2 if wide else 1) * c["FETCH_SIZE"] * 1024
-        ent["fetch_correction"] = "x2 (16 B/lane loads)" if wide else "x1 (4 B/lane loads, uncalibrated)"
+        # FETCH_SIZE reports half of the bytes of coalesced streaming reads on gfx950 (MI355X_MICROARCH.md: 16 B/lane); round 4 calibrated the
+        # first layer's width too (tools/fetch_calib_probe.hip: 1 GiB read once with 4 B per lane -> FETCH_SIZE 0.5 GiB, like 16 B per lane).
+        # Rounds 1-3 took the first layer's counter as reported ("x1, uncalibrated") and under-stated its traffic by its input bytes.
+        ent["fetch_bytes"] = 2 * c["FETCH_SIZE"] * 1024
+        ent["fetch_correction"] = "x2 (calibrated for 4 B/lane and 16 B/lane loads: tools/fetch_calib_probe.hip)"
         ent["write_bytes"] = c["WRITE_SIZE"] * 1024
         ent["hbm_bytes_per_launch"] = round(ent["fetch_bytes"] + ent["write_bytes"])
     if cyc:
