@@ -50,6 +50,7 @@ WORKLOADS = {
 # CU count at run time: 2 x 256 = 512 on an MI355X (not a constant of this chip).
 PLAN = {"sesr_x2_1080p": (3, 2), "nrdm_3_540p": (3, 2), "sesr_x4_540p": (3, 2), "nrdm6_sesrx2_540p": (3, 2)}      # (streams, slots per CU): same-box A/Bs, profiles/README.md
 PLAN_DEFAULT = (2, 0)
+GROUP = {"nrdm_3_540p": 8, "sesr_x4_540p": 8}      # frames per launch sequence in --submit many (profiles/README.md, round 4); 1 elsewhere
 
 
 def launch_bytes_per_px(bundle, first, count, in_f32):
@@ -111,6 +112,10 @@ def main():
                     help="HIP streams the steps are enqueued on round-robin (frames are independent; each stream has "
                          "its own workspace and output buffer) -- fills the launch/prologue/tail gaps between kernels.  0 = the "
                          "workload's tuned plan (PLAN): 3 for the single-frame workloads, 2 for the 32-frame batch")
+    ap.add_argument("--group", type=int, default=0,
+                    help="--submit many, single-image frames: up to this many consecutive frames of a stream become the images of ONE launch sequence "
+                         "(sesrq_forward_many with a workspace for that many frames; separate frame buffers, pointer table in the kernel arguments).  "
+                         "0 = the workload's plan (GROUP): 1 at 1080p, 8 for the 540p single-frame workloads, whose launches' fixed cost is a third of their time")
     ap.add_argument("--workload", default="sesr_x2_1080p", choices=sorted(WORKLOADS))
     ap.add_argument("--engine", default="auto", choices=["auto", "dot4", "mfma"])
     ap.add_argument("--no-fuse", action="store_true", help="one launch per layer (no fused hidden trio)")
@@ -135,6 +140,8 @@ def main():
     if args.repeats <= 0:
         args.repeats = max(5, -(-1500 // max(1, args.steps)))
     plan_streams, plan_slots_per_cu = PLAN.get(args.workload, PLAN_DEFAULT)
+    if args.group <= 0:
+        args.group = GROUP.get(args.workload, 1)
     if args.streams <= 0:
         args.streams = plan_streams
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -206,7 +213,9 @@ def main():
     if submit_many:
         import math
         period = POOL * NS // math.gcd(POOL, NS)
-        sub = engines[0].submission([pool[i % POOL] for i in range(period)], [outs[i % NS][0] for i in range(period)], streams)
+        # every frame of the period gets an output buffer of its own (frames of one stream may share a launch: --group)
+        outs_many = [outs[i][0] if i < NS else torch.empty(shapes[0], dtype=torch.int8, device=dev) for i in range(period)]
+        sub = engines[0].submission([pool[i % POOL] for i in range(period)], outs_many, streams, group=max(1, args.group) if B == 1 else 1)
 
     def step_many(n):
         sub.enqueue(n, first=counter[0])
@@ -361,7 +370,7 @@ def main():
                   "host_enqueue_sample_steps": res["host_enqueue_sample_steps"], "repeats": args.repeats, "blocks_fps": [round(args.steps * total_frames_per_step / e, 1) for e in res["elapsed"]], "spread": {"min": round(fps_all[0], 2), "median": round(fps, 2), "max": round(fps_all[-1], 2)},
                   "config": {"workload": desc, "name": args.workload, "frames_per_step_per_gpu": B, "frames_per_step": total_frames_per_step,
                              "streams": NS, "wg_budget": args.wg_budget, "hip_graph": bool(graphs),
-                             "submit": "sesrq_forward_many: one call per timed block of K steps" if sub else "sesrq_forward per step", "input_pool": f"{POOL} distinct resident frames, rotated per step",
+                             "submit": (f"sesrq_forward_many: one call per timed block of K steps, up to {sub.group} frame(s) of a stream per launch sequence" if sub else "sesrq_forward per step"), "input_pool": f"{POOL} distinct resident frames, rotated per step",
                              "in": [B, cin, H, W], "out": list(shapes[-1]), "input_dtype": "f32", "output_dtype": "i8",
                              "weights": [("reference random-init net, calibrated by the reference" if "rand" in f else
                                           "reference checkpoint, calibrated by this package (parity unpinned)" if "bundle" in f else

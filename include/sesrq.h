@@ -145,7 +145,11 @@ int sesrq_forward(const sesrq_net *net, const void *in, int in_dtype, void *out_
  * crossing of the language boundary per batch instead of one per frame, the launch arguments of the net built once per call.  The
  * reference has no counterpart (it is batch-1, quan_func.py:349, 373); per frame the bytes are sesrq_forward's.  Every frames[k].in is an
  * (N, Cin, H, W) buffer of in_dtype, out_q / out_f as in sesrq_forward (either may be NULL, not both).  Caller-owned buffers, no
- * allocation, no synchronisation.  Returns non-zero at the first frame that fails (earlier frames stay enqueued). */
+ * allocation, no synchronisation.  Returns non-zero at the first frame that fails (earlier frames stay enqueued).
+ * Grouping: with N == 1 and a workspace of sesrq_workspace_bytes(net, G, H, W) bytes, G <= 8, up to G consecutive frames of a stream
+ * become the G images of ONE launch sequence (their buffers stay where they are: a pointer table in the kernel arguments of the first and
+ * the last layer) -- the same kernels and bytes, the launches' fixed cost once per group.  A workspace for one frame keeps one launch
+ * sequence per frame. */
 typedef struct sesrq_frame_io {
     const void *in;
     void *out_q;

@@ -496,9 +496,20 @@ size_t sesrq_workspace_bytes(const sesrq_net *net, int N, int H, int W) {
     return ws_layout(net, N, H, W).total;
 }
 
+// Can the frames of several caller buffers be the images of one launch (ConvArgs::ft)?  Only the MFMA first- and last-layer kernels read
+// the table: the first layer needs its MFMA kernel (the proven division form), the last layer an MFMA shape.
+static bool groupable(const sesrq_net *net) {
+    const LayerPlan &l0 = net->layers[0], &ll = net->layers[net->L - 1];
+    return net->engine != SESRQ_ENGINE_DOT4 && l0.mfma_kind != MFMA_NONE && net->fd.ok && ll.mfma_kind != MFMA_NONE;
+}
+
+// ft != NULL: the launch's N = ft->n images are the frames ft->in[k] -> ft->out_q[k] / ft->out_f[k] (in / out_q / out_f = frame 0's,
+// for the null checks and as the "this output exists" flags)
 static int forward_impl(const sesrq_net *net, const void *in, int in_dtype, void *out_q, void *out_f, int N, int H, int W,
-                        void *workspace, size_t workspace_bytes, void *stream, const sesrq_taps *taps, hipEvent_t *ev) {
+                        void *workspace, size_t workspace_bytes, void *stream, const sesrq_taps *taps, hipEvent_t *ev,
+                        const FrameTable *ft = nullptr) {
     if (!net || !in || !workspace) { set_error("sesrq_forward: null argument"); return 1; }
+    if (ft && (taps || !groupable(net) || ft->n != N || N > SESRQ_GROUP_MAX)) { set_error("sesrq_forward: frame table not applicable"); return 1; }
     if (!out_q && !out_f) { set_error("sesrq_forward: both outputs are NULL"); return 1; }
     if (net->anchor_add && in_dtype != SESRQ_F32) { set_error("sesrq_forward: anchor add needs the fp32 input frame"); return 1; }
     if (N < 1 || H < 1 || W < 1) { set_error("sesrq_forward: N, H, W must be positive"); return 1; }
@@ -579,6 +590,7 @@ static int forward_impl(const sesrq_net *net, const void *in, int in_dtype, void
         a.rc_in = bufRC;
         a.out_q = out_q; a.out_f = (float *)out_f;
         a.anchor = (net->anchor_add && in_dtype == SESRQ_F32) ? (const float *)in : nullptr;
+        if (ft && (k == 0 || k == L - 1)) a.ft = *ft;
         if (taps) {
             a.dbg_pe = (int *)taps->pe_out[k];
             a.dbg_add = (int *)taps->pe_add[k];
@@ -632,16 +644,40 @@ namespace {
 struct SubmitJob {
     const sesrq_net *net; const sesrq_frame_io *frames; int count, first, stride, in_dtype, N, H, W;
     void *ws; size_t ws_bytes; void *stream;
+    int group;               // frames of this stream per launch (1 = one sesrq_forward per frame)
+    int next;                // the stream's next frame
     int rc = 0, bad = -1; std::string err;
 };
-static int run_job(SubmitJob &j) {
-    for (int k = j.first; k < j.count; k += j.stride)
-        if (forward_impl(j.net, j.frames[k].in, j.in_dtype, j.frames[k].out_q, j.frames[k].out_f, j.N, j.H, j.W, j.ws, j.ws_bytes, j.stream,
-                         nullptr, nullptr)) {
-            j.rc = 1; j.bad = k; j.err = sesrq_last_error();
-            return 1;
+// one launch sequence of the job: the next frame of its stream, or the next `group` frames as the images of one launch sequence (same
+// kernels, N = g, pointer table).  false = nothing left (or an error: j.rc)
+static bool job_step(SubmitJob &j) {
+    const int k = j.next;
+    if (k >= j.count || j.rc) return false;
+    int g = 1;
+    FrameTable ft;
+    ft.n = 0;
+    if (j.group > 1) {
+        const sesrq_frame_io &f0 = j.frames[k];
+        for (g = 0; g < j.group && k + g * j.stride < j.count; ++g) {
+            const sesrq_frame_io &f = j.frames[k + g * j.stride];
+            if (!f.in || (f.out_q != nullptr) != (f0.out_q != nullptr) || (f.out_f != nullptr) != (f0.out_f != nullptr)) break;
+            ft.in[g] = f.in; ft.out_q[g] = f.out_q; ft.out_f[g] = (float *)f.out_f;
         }
-    return 0;
+        if (g < 1) g = 1;
+        ft.n = g > 1 ? g : 0;
+    }
+    const sesrq_frame_io &f = j.frames[k];
+    if (forward_impl(j.net, f.in, j.in_dtype, f.out_q, f.out_f, ft.n ? g : j.N, j.H, j.W, j.ws, j.ws_bytes, j.stream, nullptr, nullptr,
+                     ft.n ? &ft : nullptr)) {
+        j.rc = 1; j.bad = k; j.err = sesrq_last_error();
+        return false;
+    }
+    j.next = k + g * j.stride;
+    return true;
+}
+static int run_job(SubmitJob &j) {
+    while (job_step(j)) {}
+    return j.rc;
 }
 class SubmitPool {
     // A worker spins on its job slot for SPIN_US after finishing a job (the bench hands over a block of frames every ~1 ms: a condition
@@ -729,28 +765,25 @@ int sesrq_forward_many(const sesrq_net *net, const sesrq_frame_io *frames, int c
     if (count < 0 || n_streams < 1 || n_streams > 64) { set_error("sesrq_forward_many: count must be >= 0 and n_streams in 1..64"); return 1; }
     for (int s = 0; s < std::min(n_streams, count); ++s)
         if (!workspaces[s]) { set_error("sesrq_forward_many: null workspace"); return 1; }
-    // SESRQ_SUBMIT_THREADS=0: everything from the calling thread (frame order k = 0, 1, 2, ...); default: one thread per stream when a
-    // stream gets at least two frames (fewer: waking a thread costs more than the launches it takes over)
+    // Frames per launch: a workspace that holds G > 1 single-image frames lets up to G consecutive frames of a stream share one launch
+    // sequence (pointer table in the kernel arguments, ConvArgs::ft): the launches' fixed cost is paid once per group.
+    int group = 1;
+    if (N == 1 && groupable(net))
+        while (group < SESRQ_GROUP_MAX && ws_layout(net, group + 1, H, W).total <= workspace_bytes) ++group;
+    // SESRQ_SUBMIT_THREADS=0: everything from the calling thread; default: one thread per stream when a stream gets at least two
+    // launch sequences (fewer: waking a thread costs more than the launches it takes over)
     static const int threads_knob = env_knob("SESRQ_SUBMIT_THREADS", 1, 0, 1);
-    std::vector<SubmitJob> jobs;
     if (threads_knob && n_streams > 1) submit_pool().ensure((size_t)n_streams - 1);
-    const bool pooled = threads_knob && n_streams > 1 && count >= 2 * n_streams;
-    const int nj = pooled ? n_streams : 1;
-    if (pooled) {
-        for (int s = 0; s < n_streams; ++s)
-            jobs.push_back(SubmitJob{net, frames, count, s, n_streams, in_dtype, N, H, W, workspaces[s], workspace_bytes, streams[s]});
-        if (!submit_pool().run(jobs)) jobs.clear();
-    }
-    if (jobs.empty()) {      // one thread: frames in order, frame k on stream k % n_streams
-        for (int k = 0; k < count; ++k) {
-            const int s = k % n_streams;
-            if (forward_impl(net, frames[k].in, in_dtype, frames[k].out_q, frames[k].out_f, N, H, W, workspaces[s], workspace_bytes, streams[s],
-                             nullptr, nullptr)) {
-                set_error("sesrq_forward_many: frame " + std::to_string(k) + ": " + sesrq_last_error());
-                return 1;
-            }
+    std::vector<SubmitJob> jobs;
+    const bool pooled = threads_knob && n_streams > 1 && count >= 2 * n_streams * group;
+    const int nj = std::min(n_streams, std::max(count, 1));
+    for (int s = 0; s < nj; ++s)
+        jobs.push_back(SubmitJob{net, frames, count, s, n_streams, in_dtype, N, H, W, workspaces[s], workspace_bytes, streams[s], group, s});
+    if (!(pooled && submit_pool().run(jobs))) {      // one thread: the streams take turns, one launch sequence each
+        for (bool any = true; any;) {
+            any = false;
+            for (auto &j : jobs) any |= job_step(j);
         }
-        return 0;
     }
     int bad = -1;
     for (int j = 0; j < nj; ++j)

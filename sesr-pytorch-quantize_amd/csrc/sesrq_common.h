@@ -118,6 +118,17 @@ bool prove_direct_requant(unsigned M, unsigned n);
 bool prove_single_requant(unsigned M, unsigned n);
 FastDiv reciprocal_form(float s, int zero);
 
+// Frames of separate caller buffers as the images of ONE launch (sesrq_forward_many, round 4): n > 0 = image k of the launch reads its
+// frame from in[k] and writes its result to out_q[k] / out_f[k] instead of the k-th slice of one contiguous batch.  Only the first layer
+// (frame in) and the last layer (frame out, anchor) look at it; everything between is the library's own contiguous workspace.
+constexpr int SESRQ_GROUP_MAX = 8;
+struct FrameTable {
+    int n;
+    const void *in[SESRQ_GROUP_MAX];
+    void *out_q[SESRQ_GROUP_MAX];
+    float *out_f[SESRQ_GROUP_MAX];
+};
+
 // Per-launch arguments of one conv layer.  Lives in the kernarg segment (SGPR loads).
 struct ConvArgs {
     const void *in;          // SRC_NHWC16: uint4 per pixel ; SRC_F32/SRC_I8: NCHW planes
@@ -157,6 +168,7 @@ struct ConvArgs {
     int relu;
     int ps;                  // EPI_LAST pixel shuffle factor
     int add_const[SESRQ_MAX_CH];
+    FrameTable ft;           // MFMA first / last layer kernels only (ft.n == 0: one contiguous batch at in / out_q / out_f)
 };
 
 // fused hidden trio (sesrq_trio.hip): three consecutive 3x3 16->16 merged layers in one launch

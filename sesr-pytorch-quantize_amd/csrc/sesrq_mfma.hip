@@ -59,8 +59,11 @@ struct LastStore {
         constexpr int r2 = R * R;
         const int Ho = a.H * R, Wo = a.W * R, cout = a.oc / r2;
         const size_t img = (size_t)cout * Ho * Wo;
-        rq = __builtin_amdgcn_make_buffer_rsrc((char *)a.out_q + (size_t)n_img * img, 0, a.out_q ? (int)img : 0, 0x00020000);
-        rf = __builtin_amdgcn_make_buffer_rsrc((char *)a.out_f + (size_t)n_img * img * 4, 0, a.out_f ? (int)(img * 4) : 0, 0x00020000);
+        // image n_img of the launch: the n_img-th slice of one batch, or a frame buffer of its own (ConvArgs::ft, sesrq_forward_many)
+        char *bq = a.ft.n ? (char *)a.ft.out_q[n_img] : (char *)a.out_q + (size_t)n_img * img;
+        char *bf = a.ft.n ? (char *)a.ft.out_f[n_img] : (char *)a.out_f + (size_t)n_img * img * 4;
+        rq = __builtin_amdgcn_make_buffer_rsrc(bq, 0, a.out_q ? (int)img : 0, 0x00020000);
+        rf = __builtin_amdgcn_make_buffer_rsrc(bf, 0, a.out_f ? (int)(img * 4) : 0, 0x00020000);
         row_elems = __builtin_amdgcn_readfirstlane(R * Wo);      // pinned to an SGPR: the row's store offset is then scalar arithmetic
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -69,7 +72,7 @@ struct LastStore {
             vo[i] = (o < a.oc && gx < a.W) ? (c * Ho + ii + lane_row * R) * Wo + gx * R + jj : (int)0x10000000;   // stays out of range times 4
             va[i] = (o < a.oc && gx < a.W) ? c * a.H * a.W + gx + lane_row * a.W : 0;
         }
-        anc = a.anchor ? a.anchor + (size_t)n_img * cout * a.H * a.W : nullptr;
+        anc = a.anchor ? (a.ft.n ? (const float *)a.ft.in[n_img] : a.anchor + (size_t)n_img * cout * a.H * a.W) : nullptr;
     }
     // the shuffle factor is a constant in each branch: the slot decode costs shifts, not integer divisions
     template <int NV = 4>
@@ -728,13 +731,14 @@ struct StageFrame {
     __device__ __forceinline__ void init(const ConvArgs &a, int n_img, int x0, int tid) {
         const size_t HW = (size_t)a.H * a.W;
         const size_t img = HW * a.ic * ESZ;
-        rs = __builtin_amdgcn_make_buffer_rsrc((char *)const_cast<void *>(a.in) + (size_t)n_img * img, 0, (int)img, 0x00020000);
+        char *frame = a.ft.n ? (char *)const_cast<void *>(a.ft.in[n_img]) : (char *)const_cast<void *>(a.in) + (size_t)n_img * img;      // ConvArgs::ft
+        rs = __builtin_amdgcn_make_buffer_rsrc(frame, 0, (int)img, 0x00020000);
         row_bytes = a.W * ESZ;
         plane_bytes = (int)(HW * ESZ);
         if constexpr (ZPAD) {
 #pragma unroll
             for (int c = 0; c < (NCH < 4 ? NCH : 4); ++c)
-                rsp[c] = __builtin_amdgcn_make_buffer_rsrc((char *)const_cast<void *>(a.in) + (size_t)n_img * img + (size_t)(c < a.ic ? c : 0) * plane_bytes, 0, plane_bytes, 0x00020000);
+                rsp[c] = __builtin_amdgcn_make_buffer_rsrc(frame + (size_t)(c < a.ic ? c : 0) * plane_bytes, 0, plane_bytes, 0x00020000);
         }
         if constexpr (SRC != SRC_I8) {
             qc.xlo = pin(a.fd.xlo); qc.xhi = pin(a.fd.xhi); qc.r = pin(a.fd.r); qc.ns = pin(-a.s_in); qc.r2 = pin(a.fd.r2); qc.z = pin(a.z_in);

@@ -62,7 +62,7 @@ class GraphedForward:
 class Submission:
     """Frames, buffers and streams of Engine.submission(), laid out once as the C arrays sesrq_forward_many takes."""
 
-    def __init__(self, engine, frames, outs_q, outs_f, streams):
+    def __init__(self, engine, frames, outs_q, outs_f, streams, group=1):
         if not frames or not streams or len(frames) != len(outs_q) or (outs_f is not None and len(outs_f) != len(frames)):
             raise ValueError("submission: frames / outputs / streams do not match")
         if len(frames) % len(streams):
@@ -84,7 +84,10 @@ class Submission:
             j = k % self.n
             self.io[k] = _lib.FrameIO(frames[j].data_ptr(), outs_q[j].data_ptr(), outs_f[j].data_ptr() if outs_f is not None else None)
         S = len(streams)
-        self.ws = [engine.workspace(N, H, W, s) for s in range(S)]
+        if group < 1 or (group > 1 and N != 1):
+            raise ValueError("submission: group >= 1, and grouping needs single-image frames")
+        self.group = int(group)
+        self.ws = [engine.workspace(N * self.group, H, W, s) for s in range(S)]       # room for `group` frames per launch sequence
         self.ws_bytes = self.ws[0].numel()
         # the library maps frame k of a call to streams[k % S]: a window that starts at frame f of the list gets the arrays rotated by f % S
         self.ws_rot = [(C.c_void_p * S)(*[self.ws[(r + i) % S].data_ptr() for i in range(S)]) for r in range(S)]
@@ -266,12 +269,14 @@ class Engine:
 
     __call__ = forward
 
-    def submission(self, frames, outs_q, streams, outs_f=None):
+    def submission(self, frames, outs_q, streams, outs_f=None, group: int = 1):
         """A prepared batch of independent forwards for sesrq_forward_many: frame k = frames[k] -> outs_q[k] (/ outs_f[k]) on
         streams[k % len(streams)] with workspace slot k % len(streams).  Returns a Submission; .enqueue(count, first=0) issues frames
         first .. first+count-1 of the (cyclically repeated) list with ONE call into the library -- for callers whose frames are so small
-        that the host's per-call cost bounds the rate.  Caller-owned persistent buffers; the caller fences the streams."""
-        return Submission(self, frames, outs_q, outs_f, streams)
+        that the host's per-call cost bounds the rate.  group = G > 1 (single-image frames only): the per-stream workspaces are sized
+        for G frames, and the library then runs up to G consecutive frames of a stream as the images of one launch sequence.
+        Caller-owned persistent buffers; the caller fences the streams."""
+        return Submission(self, frames, outs_q, outs_f, streams, group)
 
     def capture(self, x: torch.Tensor, want_q: bool = True, want_f: bool = False, slot: int = 0, downstream=()):
         """Capture one forward on `x` (and then, optionally, the chained `downstream` engines on its int8 output) as a HIP

@@ -804,6 +804,43 @@ def test_forward_many_gives_sesrq_forward_bytes():
     torch.cuda.synchronize()
     for k in range(F):
         assert torch.equal(outs8[k], want[k][0]), k
+    # grouping: a workspace for G frames lets the library run up to G consecutive frames of a stream as the images of ONE launch sequence
+    # (pointer table in the kernel arguments of the first and the last layer): same bytes, also for a remainder group and an fp32 output
+    for kind, shape, G in (("sesr_x4", (1, 1, 45, 130), 4), ("sesr_x2", (1, 3, 33, 70), 8), ("nrdm", (1, 3, 40, 64), 3)):
+        net2 = O.synth_net(kind, 23)
+        e2 = sesrq.Engine(bundle_from_oracle(net2), _dev(), wg_budget=64)
+        F2 = 14
+        xs2 = [torch.from_numpy(rand_frame(shape, 300 + k)).to(_dev()) for k in range(F2)]
+        want2 = [e2.forward(x) for x in xs2]
+        o2 = [torch.zeros_like(want2[0][0]) for _ in range(F2)]
+        f2 = [torch.zeros_like(want2[0][1]) for _ in range(F2)]
+        st2 = streams[:2]
+        torch.cuda.synchronize()
+        sub2 = e2.submission(xs2, o2, st2, outs_f=f2, group=G)
+        assert sub2.ws[0].numel() >= G * e2.workspace(1, shape[2], shape[3], 9).numel() - 4096
+        sub2.enqueue(F2)                                  # 7 frames per stream: groups of G and a remainder
+        torch.cuda.synchronize()
+        for k in range(F2):
+            assert torch.equal(o2[k], want2[k][0]) and torch.equal(f2[k], want2[k][1]), (kind, G, k)
+        for o in o2:
+            o.zero_()
+        torch.cuda.synchronize()
+        sub2.enqueue(F2 - 3, first=2)                    # a window inside the cycle: every frame still lands in ITS buffers
+        torch.cuda.synchronize()
+        for k in range(2, F2 - 1):
+            assert torch.equal(o2[k], want2[k][0]), (kind, G, k)
+    # the x2 anchor add reads each frame's OWN input through the table
+    neta = O.synth_net("sesr_x2", 3)
+    ea = sesrq.Engine(bundle_from_oracle(neta), _dev(), anchor_add=True)
+    xa = [torch.from_numpy(rand_frame((1, 3, 20, 50), 400 + k)).to(_dev()) for k in range(4)]
+    wa = [ea.forward(x) for x in xa]
+    oa = [torch.zeros_like(wa[0][0]) for _ in range(4)]
+    fa = [torch.zeros_like(wa[0][1]) for _ in range(4)]
+    torch.cuda.synchronize()
+    ea.submission(xa, oa, streams[:1], outs_f=fa, group=4).enqueue(4)
+    torch.cuda.synchronize()
+    for k in range(4):
+        assert torch.equal(oa[k], wa[k][0]) and torch.equal(fa[k], wa[k][1]), k
     # errors: a bad frame is reported with its index
     import ctypes as C
     io = (_lib.FrameIO * 2)(_lib.FrameIO(xs[0].data_ptr(), outs[0].data_ptr(), None), _lib.FrameIO(xs[1].data_ptr(), None, None))
