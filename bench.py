@@ -213,9 +213,16 @@ def main():
     if submit_many:
         import math
         period = POOL * NS // math.gcd(POOL, NS)
-        # every frame of the period gets an output buffer of its own (frames of one stream may share a launch: --group)
-        outs_many = [outs[i][0] if i < NS else torch.empty(shapes[0], dtype=torch.int8, device=dev) for i in range(period)]
-        sub = engines[0].submission([pool[i % POOL] for i in range(period)], outs_many, streams, group=max(1, args.group) if B == 1 else 1)
+        # output buffers: one per stream as in the per-step path; with --group G the G frames that may share a launch sequence (consecutive
+        # frames of one stream) get one each: frame i -> buffer (i % NS, (i // NS) % G)
+        G = max(1, args.group) if B == 1 else 1
+        obuf = {(sl, 0): outs[sl][0] for sl in range(NS)}
+        for sl in range(NS):
+            for j in range(1, G):
+                obuf[(sl, j)] = torch.empty(shapes[0], dtype=torch.int8, device=dev)
+        while (period // NS) % G:                 # whole groups per period, so that a buffer is never written twice inside one launch sequence
+            period += POOL * NS // math.gcd(POOL, NS)
+        sub = engines[0].submission([pool[i % POOL] for i in range(period)], [obuf[(i % NS, (i // NS) % G)] for i in range(period)], streams, group=G)
 
     def step_many(n):
         sub.enqueue(n, first=counter[0])
