@@ -27,6 +27,19 @@
 
 namespace sesrq {
 
+// Diagnostic build only (-DSESRQ_STAMPS, make stamps): EVERY wave of every workgroup records s_memtime at the phase boundaries of its
+// first 12 full steps into a device array no other code reads (tools/trio_stamps.py) -- where a step's cycles go, barrier waits included.
+#ifdef SESRQ_STAMPS
+__device__ unsigned long long g_trio_stamps[1024 * 4 * 12 * 8];
+#define TSTAMP(k)                                                                                                         \
+    if (l == 0 && stamp_step < 12) {                                                                                      \
+        const unsigned wg_ = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;                              \
+        if (wg_ < 1024) g_trio_stamps[((wg_ * 4 + w) * 12 + stamp_step) * 8 + (k)] = __builtin_amdgcn_s_memtime();          \
+    }
+#else
+#define TSTAMP(k)
+#endif
+
 constexpr int TV = 60;            // valid output columns per strip
 constexpr int TH = 8;             // rows per step
 constexpr int TP = 66;            // LDS row pitch (pixels): computed columns -1 .. 64
@@ -270,10 +283,19 @@ __global__ __launch_bounds__(256) void mfma_trio_kernel(const TrioArgs a) {
         __syncthreads();
     }
     int Y = y_begin;
+#ifdef SESRQ_STAMPS
+    int stamp_step = 0;
+#endif
+    // Window shifts (rows TH, TH+1 -> rows 0, 1) are split around a barrier each: the two rows are READ in front of the barrier behind which
+    // they may be overwritten and WRITTEN behind it, so the LDS round trip runs while the wave waits for the others.  Stamps
+    // (tools/trio_stamps.py): as "read; wait; write" at the top of phases a and c the shifts of bufB / bufA cost ~200 cycles each of a
+    // 6000-cycle step (phase a 1870 cycles against phase b's 1370 for the same arithmetic).
+    int4 shB = make_int4(0, 0, 0, 0);
+    if (tid < 2 * TP) shB = bufB[TH * TP + tid];
     for (; y_end - Y >= TH; Y += TH) {
+        TSTAMP(0)
         const bool more = Y + TH < y_end;                        // another step (full or half) follows
         if (more) st.load<false>(a, Y + TH + 3);                 // its new input rows, consumed after the first barrier
-        shift(bufB);                                             // layer-b rows Y-1, Y (phase c of the previous step is done)
         v4u rcp[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
         if constexpr (RCW) rc_from_window(IC8(), rcp);           // bufI = rows Y+1 .. Y+10 until the first barrier
         const bool nopad = strip_in && (Y + TH + 2 <= a.H);      // wave-uniform: rows Y+1 .. Y+9, all 64 columns inside
@@ -281,25 +303,43 @@ __global__ __launch_bounds__(256) void mfma_trio_kernel(const TrioArgs a) {
         else inner(IC0(), IC0(), IC8(), bufI, bufA, Y + 2, std::true_type());
         int4 shI = make_int4(0, 0, 0, 0);
         if (tid < 2 * TP) shI = bufI[TH * TP + tid];
+        TSTAMP(1)
         __syncthreads();
-        if (more) {
-            if (tid < 2 * TP) bufI[tid] = shI;
-            st.store<false>(bufI, a.pad_in, tid);
-        }
+        TSTAMP(2)
+        if (tid < 2 * TP) bufB[tid] = shB;                       // layer-b rows Y-1, Y: every wave has left phase c of the previous step
+        if (more && tid < 2 * TP) bufI[tid] = shI;
         if constexpr (!RCW) rc_fetch(IC8(), Y, rcp);             // in flight during phase b
+        TSTAMP(3)
         if (nopad) inner(IC1(), IC0(), IC8(), bufA, bufB, Y + 1, std::false_type());
         else inner(IC1(), IC0(), IC8(), bufA, bufB, Y + 1, std::true_type());
+        // The next step's input rows go into the window BEHIND phase b (nobody reads bufI between barrier 1 and the next step): their loads,
+        // issued at the top of the step, then have two phases to arrive.  Stamps (tools/trio_stamps.py): written right behind barrier 1 the
+        // store took 510 cycles of a 6050-cycle step (p90 912), most of it waiting for the loads.
+        if (more) st.store<false>(bufI, a.pad_in, tid);
+        int4 shA = make_int4(0, 0, 0, 0);
+        if (tid < 2 * TP) shA = bufA[TH * TP + tid];             // layer-a rows Y+8, Y+9 (phase a, visible since barrier 1)
+        TSTAMP(4)
         __syncthreads();
-        shift(bufA);
+        TSTAMP(5)
+        if (tid < 2 * TP) bufA[tid] = shA;                       // phase b has read rows 0, 1
         outer(IC8(), Y, rcp);
-        __syncthreads();
+        if (tid < 2 * TP) shB = bufB[TH * TP + tid];             // layer-b rows Y+7, Y+8 (phase b, visible since barrier 2)
+        TSTAMP(6)
+        // NO barrier here (round 4: two per step instead of three).  What follows touches nothing phase c still reads: the next phase a reads
+        // bufI (complete since barrier 2) and writes bufA rows 2.. (phase b is done with them since barrier 2), the next rc window reads
+        // bufI; bufB -- the one buffer phase c reads -- is written again only behind the NEXT barrier 1 (rows 0, 1 from shB, then phase b).
+        // A fast wave starts its next phase a (MFMA-heavy) beside the others' phase c (table look-ups, stores).
+        TSTAMP(7)
+#ifdef SESRQ_STAMPS
+        ++stamp_step;
+#endif
     }
     if (Y < y_end) {                                             // the closing half step: output rows Y .. Y+3
-        shift(bufB);
         v4u rcp[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
         if constexpr (RCW) rc_from_window(IC4(), rcp);
         inner(IC0(), IC0(), IC4(), bufI, bufA, Y + 2, std::true_type());
         __syncthreads();
+        if (tid < 2 * TP) bufB[tid] = shB;                       // behind the barrier: a slow wave may still have been in the last step's phase c
         if constexpr (!RCW) rc_fetch(IC4(), Y, rcp);
         inner(IC1(), IC0(), IC4(), bufA, bufB, Y + 1, std::true_type());
         __syncthreads();
@@ -325,6 +365,12 @@ static void launch_trio_k(K kern, TrioArgs a, hipStream_t st) {
     dim3 grid(strips, (int)k, a.N);
     launch_kernel(kern, grid, dim3(256), (unsigned)lds, st, a);
 }
+
+#ifdef SESRQ_STAMPS
+extern "C" int sesrq_debug_fetch_trio_stamps(void *host, size_t bytes) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_trio_stamps), std::min(bytes, sizeof(g_trio_stamps)), 0, hipMemcpyDeviceToHost);
+}
+#endif
 
 int launch_trio(const TrioArgs &a, int epi_c, hipStream_t st) {
     if ((size_t)a.H * a.W * 16 >= ((size_t)1 << 28)) { set_error("trio: frame too large for 32-bit buffer offsets (H*W must stay below 2^24 pixels)"); return 1; }
