@@ -138,3 +138,19 @@ def test_backend_failure_is_a_clean_exit():
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
     assert r.returncode == 3, (r.returncode, r.stderr[-400:])
     assert "sesrq.dist: init_process_group(backend='nccl'" in r.stderr
+
+
+def test_run_timed_hands_whole_phases_to_step_many():
+    """--submit many: every phase of the measurement loop reaches the library in ONE piece -- W warm-up steps, the untimed host-enqueue
+    sample, then exactly K steps per timed block (world size 1: no process group)."""
+    from sesrq.dist import Group, run_timed, HOST_SAMPLE
+    os.environ.update(RANK="0", LOCAL_RANK="0", WORLD_SIZE="1")
+    calls, synced = [], []
+    res = run_timed(Group(backend="gloo"), step=lambda: calls.append("step"), steps=7, warmup=3, repeats=4, sync=lambda: synced.append(len(calls)),
+                    units_per_step=2, step_many=lambda n: calls.append(n))
+    assert calls == [3, HOST_SAMPLE] + [7] * 4, calls
+    assert len(res["elapsed"]) == 4 and res["units_per_step_total"] == 2 and res["host_enqueue_sample_steps"] == HOST_SAMPLE
+    assert res["rates"] == [7 * 2 / e for e in res["elapsed"]]
+    calls.clear()
+    run_timed(Group(backend="gloo"), step=lambda: calls.append("step"), steps=2, warmup=0, repeats=1, step_many=lambda n: calls.append(n))
+    assert calls == [HOST_SAMPLE, 2]                      # W = 0: no empty hand-over
