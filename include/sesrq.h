@@ -149,7 +149,9 @@ int sesrq_forward(const sesrq_net *net, const void *in, int in_dtype, void *out_
  * Grouping: with N == 1 and a workspace of sesrq_workspace_bytes(net, G, H, W) bytes, G <= 8, up to G consecutive frames of a stream
  * become the G images of ONE launch sequence (their buffers stay where they are: a pointer table in the kernel arguments of the first and
  * the last layer) -- the same kernels and bytes, the launches' fixed cost once per group.  A workspace for one frame keeps one launch
- * sequence per frame. */
+ * sequence per frame.  Frames that may share a launch sequence (any G consecutive frames of a stream) must not share an output buffer.
+ * Threads: every stream's frames are enqueued by a persistent library thread of its own, in order (SESRQ_SUBMIT_THREADS=0: by the
+ * caller's thread); a second sesrq_forward_many that arrives while one is running enqueues on its caller's thread. */
 typedef struct sesrq_frame_io {
     const void *in;
     void *out_q;

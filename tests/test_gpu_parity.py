@@ -829,6 +829,15 @@ def test_forward_many_gives_sesrq_forward_bytes():
         torch.cuda.synchronize()
         for k in range(2, F2 - 1):
             assert torch.equal(o2[k], want2[k][0]), (kind, G, k)
+        if kind == "sesr_x2":      # already-quantised int8 frames through the table too
+            q02 = [torch.from_numpy(O.quantize_input(x.cpu().numpy(), net2.scale[0], net2.zero[0])).to(_dev()) for x in xs2]
+            for o in o2:
+                o.zero_()
+            torch.cuda.synchronize()
+            e2.submission(q02, o2, st2, group=G).enqueue(F2)
+            torch.cuda.synchronize()
+            for k in range(F2):
+                assert torch.equal(o2[k], want2[k][0]), (kind, "int8", k)
     # the x2 anchor add reads each frame's OWN input through the table
     neta = O.synth_net("sesr_x2", 3)
     ea = sesrq.Engine(bundle_from_oracle(neta), _dev(), anchor_add=True)
