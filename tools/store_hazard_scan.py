@@ -45,6 +45,13 @@ for n, l in enumerate(lines):
             if bad and (not pat or pat in subprocess.run(["c++filt", kern2 or ""], capture_output=True, text=True).stdout):
                 hits += 1
                 print(f"{kern2}\n  line {n + 1}: {u0}   <- inline asm writes {sorted(bad)} while an MFMA issued <= 18 wait states earlier still writes it (unmodelled WAW)")
+        if not in_asm and pending and len(args0) > 1:
+            # a MODELLED instruction that reads such a register was padded by hipcc until the MFMA's result had landed: the register is
+            # settled from here on (not so an MFMA that accumulates in place, vDst == SrcC: that dependency is forwarded, not waited for)
+            mf = op0.startswith(("v_mfma", "v_smfmac"))
+            for k, a in enumerate(args0[1:], 1):
+                if mf and k == 3 and regs(a) == regs(args0[0]): continue
+                for r in regs(a): pending.pop(r, None)
         step = int(args0[0]) + 1 if op0 == "s_nop" and args0 else 1
         pending = {r: c - step for r, c in pending.items() if c > step}
         if op0.startswith(("v_mfma", "v_smfmac")) and args0:
