@@ -28,8 +28,8 @@ HOST_SAMPLE = 16      # untimed steps behind the warm-up on which the host's enq
 
 
 def run_timed(group: "Group", step, steps: int, warmup: int, repeats: int = 1, sync=None, units_per_step: float = 1.0, step_many=None):
-    """The measurement loop of bench.py, shared with the CPU tests so that on a multi-GPU node the RCCL backend is
-    the only line that has not run before:  W untimed warm-up steps, then `repeats` blocks of EXACTLY `steps` steps,
+    """The measurement loop of bench.py, shared with the CPU tests so that on a multi-GPU node RCCL between devices is
+    the only thing that has not run before:  W untimed warm-up steps, then `repeats` blocks of EXACTLY `steps` steps,
     each block bracketed by  sync() -> barrier  on both sides (local queue drained first, then the rendezvous, so every
     rank starts its clock with an idle device and stops it when ITS work is done and all ranks have arrived); the
     block's time is the MAX over ranks.  `units_per_step` = units (frames) THIS rank processes per step; the job's
@@ -78,11 +78,13 @@ def run_timed(group: "Group", step, steps: int, warmup: int, repeats: int = 1, s
 class Group:
     """Thin wrapper over torch.distributed used by bench.py; a no-op for world_size 1."""
 
-    def __init__(self, backend: Optional[str] = None, device=None, timeout_s: Optional[float] = None):
+    def __init__(self, backend: Optional[str] = None, device=None, timeout_s: Optional[float] = None, force: bool = False):
+        """force: build the process group at world size 1 too (the one-GPU box's way to run the RCCL fence: communicator creation,
+        barrier, MAX / SUM all-reduce on the device -- tests/test_00_bench_spawn.py)"""
         self.rank, self.local_rank, self.world = env_world()
         self.dist = None
         self.device = device
-        if self.world > 1:
+        if self.world > 1 or force:
             import torch.distributed as dist
             kw = {}
             if backend == "nccl" and device is not None:

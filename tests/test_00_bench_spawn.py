@@ -1,7 +1,8 @@
 """The N > 1 launch path of bench.py on the one-GPU box (runs FIRST in the -m gpu session: the child processes are started before
 this process has touched the GPU): `bench.py --gpus 2` spawns two ranks through torch.distributed.run exactly as on a multi-GPU
 node; here both ranks share the one device (--share-gpu) and the timing fence runs over gloo instead of RCCL -- frame sharding,
-fences, MAX / SUM reductions and the rank-0 JSON are the real ones.  `backend="nccl"` stays the only line that has not run."""
+fences, MAX / SUM reductions and the rank-0 JSON are the real ones.  `backend="nccl"` itself runs as a ONE-rank group (RCCL refuses two
+ranks on one device): communicator creation, barrier and the MAX / SUM all-reduces on the device; what stays unrun is xGMI between GPUs."""
 import json
 import os
 import subprocess
@@ -29,3 +30,23 @@ def test_bench_two_ranks_spawned_by_the_launcher():
     assert d["scaling"] == "weak" and d["value"] > 0
     assert d["parity"]["mismatches"] == 0 and d["parity"]["max_abs_diff_int8"] == 0
     assert d["cpu_baseline"] is None and d["e2e"] is None      # rank-0-at-N=1-only legs
+
+
+@pytest.mark.gpu
+def test_rccl_fence_on_a_one_rank_group():
+    """sesrq.dist.Group(backend="nccl") as bench.py builds it (device_id given), forced at world size 1 in a child process: RCCL
+    creates its communicator on cuda:0, the barrier and both reductions of run_timed() execute on the device, the group closes."""
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    code = ("import sys, torch; sys.path.insert(0, %r); from sesrq.dist import Group, run_timed\n"
+            "dev = torch.device('cuda:0'); torch.cuda.set_device(dev)\n"
+            "g = Group(backend='nccl', device=dev, timeout_s=120, force=True)\n"
+            "x = torch.zeros(1 << 20, device=dev)\n"
+            "r = run_timed(g, lambda: x.add_(1), steps=4, warmup=1, repeats=2, sync=torch.cuda.synchronize, units_per_step=3)\n"
+            "assert r['units_per_step_total'] == 3 and len(r['elapsed']) == 2 and g.max_over_ranks(1.5) == 1.5\n"
+            "assert float(x[0]) == 1 + 16 + 8\n"
+            "import torch.distributed as d; print('backend', d.get_backend(), flush=True); g.close()") % os.path.join(ROOT, "sesr-pytorch-quantize_amd")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert "backend nccl" in r.stdout
