@@ -75,8 +75,10 @@ struct LastStore {
         anc = a.anchor ? (a.ft.n ? (const float *)a.ft.in[n_img] : a.anchor + (size_t)n_img * cout * a.H * a.W) : nullptr;
     }
     // the shuffle factor is a constant in each branch: the slot decode costs shifts, not integer divisions
-    template <int NV = 4>
+    // FAST = 2 / 4: the kernel instance is built for that shuffle factor (no switch, no dead arms in the prologue)
+    template <int NV = 4, int FAST = 0>
     __device__ __forceinline__ void init(const ConvArgs &a, int n_img, int g, int gx, int lane_row = 0) {
+        if constexpr (FAST != 0) { init_r<FAST, NV>(a, n_img, g, gx, lane_row); return; }
         switch (a.ps) {
             case 1: init_r<1, NV>(a, n_img, g, gx, lane_row); break;
             case 2: init_r<2, NV>(a, n_img, g, gx, lane_row); break;
@@ -310,32 +312,50 @@ struct StageNHWC16 {
 // s_memtime at the phase boundaries into a buffer no other code reads (guide §7, in-kernel stamps).
 #ifdef SESRQ_STAMPS
 #define STAMP(k)                                                                                    \
-    if (a.dbg_pe && tid == 0) {                                                                     \
+    if (a.dbg_pe && tid == 0 && (k) < 15) {      /* slot 15 = kernel entry; runs longer than 4 tiles: the first 4 */ \
         int *sp = a.dbg_pe + ((bxy.y * gridDim.x + bxy.x) * 16 + (k)) * 2;                \
         sp[0] = (int)__builtin_amdgcn_s_memrealtime();                                              \
         sp[1] = (int)__builtin_amdgcn_s_memtime();                                                  \
     }
+#define STAMP_ENTRY                                                                                 \
+    if (a.dbg_pe && tid == 0) {                                                                     \
+        int *sp = a.dbg_pe + ((bxy.y * gridDim.x + bxy.x) * 16 + 15) * 2;                          \
+        sp[0] = bxy.t_entry;                                                                        \
+        sp[1] = bxy.c_entry;                                                                        \
+    }
 #else
 #define STAMP(k)
+#define STAMP_ENTRY
 #endif
 #define SESRQ_TILE_WALK(STAGE_T, BUF0, BUF1, COMPUTE) SESRQ_TILE_WALK_H(MTH, STAGE_T, BUF0, BUF1, COMPUTE)
-#define SESRQ_TILE_WALK_H(TILE_H, STAGE_T, BUF0, BUF1, COMPUTE)                                              \
+#define SESRQ_TILE_WALK_H(TILE_H, STAGE_T, BUF0, BUF1, COMPUTE)                                     \
     {                                                                                               \
-        const int row_tiles_ = (a.H + (TILE_H) - 1) / (TILE_H);      /* runs of (almost) equal length */      \
-        const int t_begin = (int)(((long long)bxy.y * row_tiles_) / gridDim.y);                \
-        const int t_end = (int)(((long long)(bxy.y + 1) * row_tiles_) / gridDim.y);            \
-        STAGE_T st;                                                                                 \
-        st.init(a, n_img, x0, tid);                                                                 \
-        STAMP(0)                                                                                    \
-        st.load_first(a, n_img, x0, t_begin * (TILE_H), tid);                                            \
-        STAMP(1)                                                                                    \
+        SESRQ_TILE_WALK_BEGIN(TILE_H, STAGE_T)                                                      \
+        SESRQ_TILE_WALK_REST(TILE_H, BUF0, BUF1, COMPUTE)                                           \
+    }
+// BEGIN: the run's bounds and the loads of its first tile.  A kernel may place it at its very top, ahead of everything else it fetches
+// (A fragments, tables, store geometry): the frame loads are then the FIRST vector-memory requests of the wave, and what the rest of the
+// prologue waits for arrives beside them instead of in front of them (round 4: 2 us from kernel entry to the first frame load of the last
+// layer, most of it dependent round trips to memory)
+#define SESRQ_TILE_WALK_BEGIN(TILE_H, STAGE_T)                                                      \
+    const int row_tiles_ = (a.H + (TILE_H) - 1) / (TILE_H);      /* runs of (almost) equal length */ \
+    const int t_begin = (int)(((long long)bxy.y * row_tiles_) / gridDim.y);                         \
+    const int t_end = (int)(((long long)(bxy.y + 1) * row_tiles_) / gridDim.y);                     \
+    STAGE_T st;                                                                                     \
+    st.init(a, n_img, x0, tid);                                                                     \
+    STAMP(0)                                                                                        \
+    STAMP_ENTRY                                                                                     \
+    st.load_first(a, n_img, x0, t_begin * (TILE_H), tid);                                           \
+    STAMP(1)
+#define SESRQ_TILE_WALK_REST(TILE_H, BUF0, BUF1, COMPUTE)                                           \
+    {                                                                                               \
         st.store(BUF0, a, tid);                                                                     \
         __syncthreads();                                                                            \
         STAMP(2)                                                                                    \
         for (int t = t_begin; t < t_end; ++t) {                                                     \
-            const int y0 = t * (TILE_H);                                                                 \
+            const int y0 = t * (TILE_H);                                                            \
             const bool cur0 = ((t - t_begin) & 1) == 0;                                             \
-            if (t + 1 < t_end) st.load(a, n_img, x0, y0 + (TILE_H), tid);                                \
+            if (t + 1 < t_end) st.load(a, n_img, x0, y0 + (TILE_H), tid);                           \
             { const int4 *cur_tile = cur0 ? BUF0 : BUF1; COMPUTE(cur_tile) }                        \
             STAMP(3 + 3 * (t - t_begin))                                                            \
             if (t + 1 < t_end) { if (cur0) st.store(BUF1, a, tid); else st.store(BUF0, a, tid); }  \
@@ -345,15 +365,10 @@ struct StageNHWC16 {
         }                                                                                           \
     }
 
-// the same walk for a stage type whose following tiles take their top halo rows from the tile under computation (StageFrame)
-#define SESRQ_TILE_WALK_CARRY(TILE_H, STAGE_T, BUF0, BUF1, COMPUTE)                                          \
+// the rest of the walk (after SESRQ_TILE_WALK_BEGIN) for a stage type whose following tiles take their top halo rows from the tile under
+// computation (StageFrame)
+#define SESRQ_TILE_WALK_CARRY_REST(TILE_H, BUF0, BUF1, COMPUTE)                                     \
     {                                                                                               \
-        const int row_tiles_ = (a.H + (TILE_H) - 1) / (TILE_H);                                      \
-        const int t_begin = (int)(((long long)bxy.y * row_tiles_) / gridDim.y);                \
-        const int t_end = (int)(((long long)(bxy.y + 1) * row_tiles_) / gridDim.y);            \
-        STAGE_T st;                                                                                 \
-        st.init(a, n_img, x0, tid);                                                                 \
-        st.load_first(a, n_img, x0, t_begin * (TILE_H), tid);                                       \
         st.store(BUF0, a, tid);                                                                     \
         __syncthreads();                                                                            \
         for (int t = t_begin; t < t_end; ++t) {                                                     \
@@ -375,6 +390,7 @@ __global__ __launch_bounds__(256) void mfma_h3_kernel(const ConvArgs a) {
     constexpr int PW = GENERAL ? SW : 0;             // planar image: row pitch 4*68 = 272 dwords = 16 mod 64 banks
     __shared__ int4 buf0[SH * SW], buf1[SH * SW];
     const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, n = l & 15, g = l >> 4;
+    kernarg_warm<ConvArgs>();
     const BlockXY bxy = xcd_block();
     const int x0 = bxy.x * MTW, n_img = blockIdx.z;
     const int4 *fr = a.afrag;
@@ -470,8 +486,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void m
     constexpr int SHB = SH + (MODE == HYB ? 1 : 0);      // hybrid: the risky PE's pairs reach one row below the tile (zero weights)
     __shared__ int4 buf0[GENERAL ? CP : SHB * SW], buf1[GENERAL ? CP : SHB * SW];      // general: 4 planes of CP dwords
     const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, n = l & 15, g = l >> 4;
+    kernarg_warm<ConvArgs>();
     const BlockXY bxy = xcd_block();
     const int x0 = bxy.x * MTW, n_img = blockIdx.z;
+    using Stage = StageNHWC16<SH, SW, 2, 0, CP, CS>;
+    SESRQ_TILE_WALK_BEGIN(MTH, Stage)
     const int4 *fr = a.afrag;
     constexpr bool BIASED = mode_biased(MODE);     // requant without v_cvt: sums carry + MAGIC_I (needs |s| < 2^22)
     int4 ac = fr[g];
@@ -496,8 +515,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void m
         for (int q = 0; q < 2; ++q) h5_pair(c, g, q, pcol[c][q], prow[c][q]);
     LastStore ls, ls1;                                  // general: one per column group of the wave
     if constexpr (EPI == EPI_LAST) {
-        if constexpr (GENERAL) { ls.template init<NV>(a, n_img, g, x0 + 32 * cg + n); ls1.template init<NV>(a, n_img, g, x0 + 32 * cg + 16 + n); }
-        else ls.template init<NV>(a, n_img, g, gx);
+        if constexpr (GENERAL) { ls.template init<NV, FAST % 10>(a, n_img, g, x0 + 32 * cg + n); ls1.template init<NV, FAST % 10>(a, n_img, g, x0 + 32 * cg + 16 + n); }
+        else ls.template init<NV, FAST % 10>(a, n_img, g, gx);
     }
     v4i AR[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
     if constexpr (MODE == HYB) {
@@ -615,8 +634,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void m
         }
     };
 #define SESRQ_COMPUTE(B) compute(B, y0);
-    using Stage = StageNHWC16<SH, SW, 2, 0, CP, CS>;
-    SESRQ_TILE_WALK(Stage, buf0, buf1, SESRQ_COMPUTE)
+    SESRQ_TILE_WALK_REST(MTH, buf0, buf1, SESRQ_COMPUTE)
 #undef SESRQ_COMPUTE
 }
 
@@ -632,6 +650,7 @@ __global__ __launch_bounds__(256) void mfma_h5p_kernel(const ConvArgs a) {
     constexpr int SH = MTH + 4;
     __shared__ int4 buf0[SH * SW], buf1[SH * SW];
     const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, n = l & 15, g = l >> 4;
+    kernarg_warm<ConvArgs>();
     const BlockXY bxy = xcd_block();
     const int x0 = bxy.x * MTW, n_img = blockIdx.z;
     const int4 *fr = a.afrag;
@@ -840,8 +859,12 @@ __device__ __forceinline__ void mfma_f5_body(const ConvArgs &a, int4 *buf0, int4
     constexpr bool GENERAL = mode_general(MODE);
     constexpr int SH = F5_SH, SWP = F5_SWP, PITCH = F5_PITCH;
     const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, n = l & 15, g = l >> 4;
+    kernarg_warm<ConvArgs>();
     const BlockXY bxy = xcd_block();
     const int x0 = bxy.x * MTW, n_img = blockIdx.z;
+    using Stage = StageFrame<SRC, SH, SWP, PITCH, NCH>;
+    static_assert(F5_SH - F5_TH == 4, "StageFrame carries SH - TH = 4 rows");
+    SESRQ_TILE_WALK_BEGIN(F5_TH, Stage)      // the frame loads of the first tile go out before anything else is fetched
     const int4 *fr = a.afrag;
     constexpr bool BIASED = mode_biased(MODE);     // requant without v_cvt: sums carry + MAGIC_I (needs |s| < 2^22)
     int4 ac = fr[g];
@@ -944,9 +967,7 @@ __device__ __forceinline__ void mfma_f5_body(const ConvArgs &a, int4 *buf0, int4
         }
     };
 #define SESRQ_COMPUTE(B) compute(B, y0);
-    using Stage = StageFrame<SRC, SH, SWP, PITCH, NCH>;
-    static_assert(F5_SH - F5_TH == 4, "StageFrame carries SH - TH = 4 rows");
-    SESRQ_TILE_WALK_CARRY(F5_TH, Stage, buf0, buf1, SESRQ_COMPUTE)
+    SESRQ_TILE_WALK_CARRY_REST(F5_TH, buf0, buf1, SESRQ_COMPUTE)
 #undef SESRQ_COMPUTE
 }
 // 4 waves per SIMD for the merged / hybrid first layer: with the default heuristics hipcc takes 141-153 VGPRs here (3 waves);

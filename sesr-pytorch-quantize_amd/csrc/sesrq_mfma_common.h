@@ -325,9 +325,39 @@ __device__ __forceinline__ void transpose4(unsigned w[4]) {
 // 25.8 MB fetched for its 24.9 MB fp32 frame -- a 64-pixel tile row is two 128-byte lines per channel plane and its halo touches two more --
 // and 16.8 -> 14.6 us; trio 43.0 -> 35.0 MB (33.2 MB of input), last layer 43.0 -> 34.8 MB, times unchanged (they are issue-bound).
 // Speed only: nothing depends on which XCD a block lands on.
+// Every 64-byte line of the kernel-argument segment requested by the FIRST instructions of the kernel, in one batch.  hipcc loads kernel
+// arguments where they are first used: the 540-byte ConvArgs reached the prologue as four to six DEPENDENT batches of scalar loads (block
+// index -> frame pointers -> geometry -> epilogue constants ...), each a miss of the scalar cache to HBM with every workgroup of the launch
+// starting at once -- 4.6 k cycles from kernel entry to the first frame load of the last layer (tools/stamps.py, round 4; with the segment
+// in host memory, HIP_FORCE_DEV_KERNARG=0, the first layer is 5 us slower: five round trips).  After this the later loads hit the cache.
+template <typename ARGS>
+__device__ __forceinline__ void kernarg_warm() {
+#ifdef SESRQ_NO_KWARM
+    return;
+#endif
+    typedef const int __attribute__((address_space(4))) *karg_t;
+    karg_t kp = (karg_t)__builtin_amdgcn_kernarg_segment_ptr();
+    constexpr int LINES = ((int)sizeof(ARGS) + 32 + 63) / 64;      // + the implicit arguments hipcc reads (grid size), which follow the struct
+    static_assert(LINES <= 12, "one asm operand per line");
+    int t[12];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) t[i] = kp[(i < LINES ? i * 16 : 0)];
+    const int last = kp[((int)sizeof(ARGS) + 32) / 4 - 1];
+    asm volatile("" ::"s"(t[0]), "s"(t[1]), "s"(t[2]), "s"(t[3]), "s"(t[4]), "s"(t[5]), "s"(t[6]), "s"(t[7]), "s"(t[8]), "s"(t[9]), "s"(t[10]),
+                 "s"(t[11]), "s"(last));
+}
+
+#ifdef SESRQ_STAMPS
+struct BlockXY { int x, y, t_entry, c_entry; };      // diagnostic build: clocks read where the kernel fetches its block index
+#else
 struct BlockXY { int x, y; };
+#endif
 __device__ __forceinline__ BlockXY xcd_block() {
     BlockXY b = {(int)blockIdx.x, (int)blockIdx.y};
+#ifdef SESRQ_STAMPS
+    b.t_entry = (int)__builtin_amdgcn_s_memrealtime();
+    b.c_entry = (int)__builtin_amdgcn_s_memtime();
+#endif
     const unsigned nx = gridDim.x, total = nx * gridDim.y, per = total >> 3;
     const unsigned id = blockIdx.y * nx + blockIdx.x;
     if (id < per * 8) {      // the last total % 8 blocks keep their place

@@ -122,6 +122,7 @@ __global__ __launch_bounds__(256) void mfma_trio_kernel(const TrioArgs a) {
     // MAGIC + 256 + the table's LDS byte address (exact: < 2^24); see epi_preres_lut
     const float lut_magic = MAGIC + 256.f + (float)(unsigned)(size_t)(const __attribute__((address_space(3))) void *)lutp;
     const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, n = l & 15, g = l >> 4;
+    kernarg_warm<TrioArgs>();
     const BlockXY bxy = xcd_block();
     const int n_img = blockIdx.z;
     const int x0 = bxy.x * TV - 2;              // frame column of computed column 0
@@ -134,8 +135,15 @@ __global__ __launch_bounds__(256) void mfma_trio_kernel(const TrioArgs a) {
     const int y_begin = a.run_unit * (int)(((long long)bxy.y * units_total) / gridDim.y);
     const int y_end = a.run_unit * (int)(((long long)(bxy.y + 1) * units_total) / gridDim.y);
     if (y_begin >= y_end) return;
-    if constexpr (LUT) {           // visible to every wave long before the first residual merge (barriers of the cold start)
-        if (threadIdx.x < 128) reinterpret_cast<int *>(lutp)[threadIdx.x] = a.merge_lut[threadIdx.x];
+    // The frame loads of the cold-start window are the FIRST vector-memory requests of the wave; the table and the A fragments follow and
+    // arrive beside them (memory returns loads in order): the prologue used to wait for the table's round trip (global load -> LDS write)
+    // before it had even asked for its first pixel.
+    TrioStage st;
+    st.init(a, n_img, x0, tid);
+    st.load<true>(a, y_begin - TH + 1);
+    int lut_word = 0;
+    if constexpr (LUT) {
+        if (threadIdx.x < 128) lut_word = a.merge_lut[threadIdx.x];
     }
 
     const int c = 16 * w + n, gx = x0 + c;
@@ -256,8 +264,6 @@ __global__ __launch_bounds__(256) void mfma_trio_kernel(const TrioArgs a) {
         if (tid < 2 * TP) { const int4 t = win[TH * TP + tid]; win[tid] = t; }
     };
 
-    TrioStage st;
-    st.init(a, n_img, x0, tid);
     using IC0 = integral_constant<int, 0>;
     using IC1 = integral_constant<int, 1>;
     using IC4 = integral_constant<int, 4>;
@@ -265,9 +271,11 @@ __global__ __launch_bounds__(256) void mfma_trio_kernel(const TrioArgs a) {
     using IC8 = integral_constant<int, 8>;
     // ---- cold start: the step before the run's first one, only the rows the first real step needs
     {
-        const int Y = y_begin - TH;
-        st.load<true>(a, Y + 1);
+        const int Y = y_begin - TH;                              // its loads (rows Y + 1 ..) went out at the top of the kernel
         st.store<true>(bufI, a.pad_in, tid);
+        if constexpr (LUT) {           // visible to every wave long before the first residual merge (barriers of the cold start)
+            if (threadIdx.x < 128) reinterpret_cast<int *>(lutp)[threadIdx.x] = lut_word;
+        }
         __syncthreads();
         if constexpr (RCW) rcc = rc_win(TH - 1);                // frame row y_begin = position 7 of the cold-start window (rows y_begin-7 ..)
         st.load<false>(a, Y + TH + 3);
