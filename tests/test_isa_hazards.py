@@ -25,6 +25,28 @@ def test_no_valu_write_behind_a_wide_store(stem, tmp_path):
     subprocess.run([HIPCC] + flags + [os.path.join(CSRC, stem + ".hip"), "-o", asm], check=True, capture_output=True)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "store_hazard_scan.py"), asm], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout[-3000:]
+    # kernarg_warm() (sesrq_mfma_common.h) touches one dword per 64-byte line of the argument segment with the kernel's first instructions:
+    # every such read must lie inside the segment the code object declares (explicit struct + the implicit arguments behind it)
+    import re
+    text = open(asm).read()
+    kernels = 0
+    for m in re.finditer(r"^(_ZN5sesrq\w+):[^\n]*\n(.*?)\.amdhsa_kernarg_size (\d+)", text, re.S | re.M):
+        body, size = m.group(2), int(m.group(3))
+        warm = []
+        for line in body.split("\n"):
+            t = line.strip()
+            if not t or t.startswith((";", ".")):
+                continue
+            mm = re.match(r"s_load_dword s\d+, s\[0:1\], (0x[0-9a-f]+|\d+)$", t)
+            if not mm:
+                break
+            warm.append(int(mm.group(1), 0))
+        if warm:
+            kernels += 1
+            warm.sort()                                   # the scheduler may permute the batch
+            assert len(warm) >= 4 and warm[0] == 0 and max(warm) + 4 <= size, (m.group(1), warm, size)
+            assert all(b - a <= 64 for a, b in zip(warm, warm[1:])), (m.group(1), warm)     # no line of the segment skipped
+    assert kernels >= 5, kernels
 
 
 def test_scanner_follows_branches_and_sees_asm_defined_operands(tmp_path):
