@@ -701,8 +701,8 @@ class SubmitPool {
             while (!(j = w->job.load(std::memory_order_acquire))) {
                 if (std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(SPIN_US)) {
                     std::unique_lock<std::mutex> lk(w->mu);
-                    w->asleep.store(true);
-                    w->cv.wait(lk, [&] { return w->job.load(std::memory_order_acquire) || w->quit; });
+                    w->asleep.store(true, std::memory_order_seq_cst);
+                    w->cv.wait(lk, [&] { return w->job.load(std::memory_order_seq_cst) || w->quit; });
                     w->asleep.store(false);
                     if (w->quit) return;
                 } else {
@@ -743,8 +743,11 @@ public:
         for (size_t i = 1; i < jobs.size(); ++i) {
             Worker *w = workers[i - 1].get();
             w->done.store(false, std::memory_order_relaxed);
-            w->job.store(&jobs[i], std::memory_order_release);
-            if (w->asleep.load()) { std::lock_guard<std::mutex> lk(w->mu); w->cv.notify_all(); }
+            // seq_cst on purpose: "publish the job, then look whether the worker sleeps" against the worker's "say asleep, then look for a
+            // job" is Dekker's pattern -- with a release store the load below may pass it (store buffer), both sides read the old value
+            // and the worker sleeps on a pending job while this thread spins on `done`
+            w->job.store(&jobs[i], std::memory_order_seq_cst);
+            if (w->asleep.load(std::memory_order_seq_cst)) { std::lock_guard<std::mutex> lk(w->mu); w->cv.notify_all(); }
         }
         run_job(jobs[0]);
         for (size_t i = 1; i < jobs.size(); ++i) {

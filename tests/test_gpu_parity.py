@@ -860,6 +860,31 @@ def test_forward_many_gives_sesrq_forward_bytes():
     torch.cuda.synchronize()
 
 
+@pytest.mark.gpu
+@pytest.mark.timeout(300)
+def test_forward_many_workers_wake_from_sleep():
+    """The submission threads of sesrq_forward_many spin for 2 ms after a batch and then sleep on a condition variable: calls spaced
+    around that boundary (0 ... 5 ms apart) must hand every batch over -- a lost wake-up would leave the caller spinning (the timeout)."""
+    import time
+    net = O.synth_net("sesr_x4", 29)
+    e = sesrq.Engine(bundle_from_oracle(net), _dev(), wg_budget=64)
+    S, F = 3, 12
+    xs = [torch.from_numpy(rand_frame((1, 1, 24, 64), 500 + k)).to(_dev()) for k in range(F)]
+    want = [e.forward(x, want_f=False)[0] for x in xs]
+    streams = [torch.cuda.Stream(device=_dev()) for _ in range(S)]
+    outs = [torch.zeros_like(want[0]) for _ in range(F)]
+    sub = e.submission(xs, outs, streams)
+    torch.cuda.synchronize()
+    for it in range(60):
+        for o in outs:
+            o.zero_()
+        torch.cuda.synchronize()
+        sub.enqueue(F)                     # 4 launch sequences per stream: the pooled path
+        torch.cuda.synchronize()
+        assert all(torch.equal(outs[k], want[k]) for k in range(F)), it
+        time.sleep((0.0, 0.0015, 0.0019, 0.002, 0.0021, 0.0025, 0.005)[it % 7])
+
+
 def test_side_stream_with_non_contiguous_input():
     """forward(stream=s): the side stream is ordered behind the producer of x, temporaries are recorded on it."""
     net = O.synth_net("sesr_x2", 9)
