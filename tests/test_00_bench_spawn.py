@@ -50,3 +50,12 @@ def test_rccl_fence_on_a_one_rank_group():
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=env)
     assert r.returncode == 0, r.stderr[-3000:]
     assert "backend nccl" in r.stdout
+
+
+@pytest.mark.gpu
+def test_soak_every_output_frame_of_the_bench_plan():
+    """tools/soak.py: the bench plan (3 streams x 512 slots, sesrq_forward_many) on 24 distinct 1080p frames, EVERY 4K output frame of 25
+    rounds compared byte for byte with the one-stream forward (whose frame 0 is checked against the C oracle): a hazard that corrupts one
+    store in 10^5 escapes a single whole-frame check (profiles/r04_soak.txt: 96 000 frames, 0 bad)."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "soak.py"), "25"], capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0 and "SOAK ok 600 frames" in r.stdout, (r.stdout[-1500:], r.stderr[-1500:])
