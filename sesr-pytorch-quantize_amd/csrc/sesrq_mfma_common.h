@@ -251,7 +251,9 @@ __device__ __forceinline__ unsigned epi_preres_lut(const int s[4], unsigned rcwo
     // + the SIGNED rc byte (v_add_u32_sdwa, WORD_0 + sign-extended BYTE_k): lut_addr + (rc + ic + 256) = the address of q4(u)
     const unsigned a0 = (fbits(c01[0]) & 0xffffu) + (unsigned)(int)(signed char)(rcword), a1 = (fbits(c01[1]) & 0xffffu) + (unsigned)(int)(signed char)(rcword >> 8);
     const unsigned a2 = (fbits(c23[0]) & 0xffffu) + (unsigned)(int)(signed char)(rcword >> 16), a3 = (fbits(c23[1]) & 0xffffu) + (unsigned)((int)rcword >> 24);
-    // bytes 0 / 2 and 1 / 3 land in the low / high halves of two registers (ds_read_u8_d16 / _d16_hi), one v_lshl_or joins them
+    // bytes 0 / 2 and 1 / 3 as the halves of two registers, joined by one v_lshl_or.  (Written for ds_read_u8_d16 / _d16_hi pairs; gfx950 runs
+    // with SRAM ECC, where a d16 load clears the register's other half, so hipcc emits four ds_read_u8 and two v_perm instead: three VALU
+    // per four bytes, the minimum for four single-byte registers)
     typedef unsigned short v2us __attribute__((ext_vector_type(2)));
     const v2us x = {(unsigned short)*(lds_u8_t)(size_t)a0, (unsigned short)*(lds_u8_t)(size_t)a2};
     const v2us y = {(unsigned short)*(lds_u8_t)(size_t)a1, (unsigned short)*(lds_u8_t)(size_t)a3};
