@@ -334,9 +334,6 @@ __device__ __forceinline__ void transpose4(unsigned w[4]) {
 // in host memory, HIP_FORCE_DEV_KERNARG=0, the first layer is 5 us slower: five round trips).  After this the later loads hit the cache.
 template <typename ARGS>
 __device__ __forceinline__ void kernarg_warm() {
-#ifdef SESRQ_NO_KWARM
-    return;
-#endif
     typedef const int __attribute__((address_space(4))) *karg_t;
     karg_t kp = (karg_t)__builtin_amdgcn_kernarg_segment_ptr();
     constexpr int LINES = ((int)sizeof(ARGS) + 32 + 63) / 64;      // + the implicit arguments hipcc reads (grid size), which follow the struct
