@@ -9,7 +9,15 @@ from sesrq.bundle import Bundle
 b = Bundle.load(os.path.join(ROOT, "tests/golden/sesr_x2_rand.crop.npz"))
 e = sesrq.Engine(b, torch.device("cuda:0"), engine=_lib.ENGINE_MFMA, fuse_hidden=False, wg_budget=int(os.environ.get('WG_BUDGET', '512')))   # stamps live in the per-layer kernels; the LAST layer's launch is what is read back
 x = torch.rand(1, 3, 1080, 1920, device="cuda")
-for _ in range(50): e.forward(x, want_f=False)      # int8 frame only: the last-layer instance bench.py times
+STREAMS = int(os.environ.get("STREAMS", "1"))
+if STREAMS > 1:      # the bench plan: FUSED engine, STREAMS streams, sesrq_forward_many for ~2 s -- the last-layer launch read back ran under that load
+    e = sesrq.Engine(b, torch.device("cuda:0"), engine=_lib.ENGINE_MFMA, wg_budget=int(os.environ.get('WG_BUDGET', '512')))
+    xs = [torch.rand(1, 3, 1080, 1920, device="cuda") for _ in range(8 * STREAMS)]
+    outs = [torch.empty(e.out_shape(1, 1080, 1920), dtype=torch.int8, device="cuda") for _ in xs]
+    sub = e.submission(xs, outs, [torch.cuda.Stream() for _ in range(STREAMS)])
+    for _ in range(int(os.environ.get("ROUNDS", "1500"))): sub.enqueue(len(xs))
+else:
+    for _ in range(50): e.forward(x, want_f=False)      # int8 frame only: the last-layer instance bench.py times
 torch.cuda.synchronize()
 lib = _lib.lib()
 buf = np.zeros(1 << 20, np.int32)
@@ -31,6 +39,10 @@ for k, nm in enumerate(names[:16]):
         v = rel[rt[:, k] != 0, k] / 100.0
         print(f"  {nm:14s} {np.median(v):7.2f} {v.min():7.2f} {v.max():7.2f}")
 dc = (ct[:, 1:] - ct[:, :-1]) & 0xffffffff
+# in-kernel shader clock (MI355X_MICROARCH.md, DVFS give-back item 6): cycles / realtime over the stamped tiles of every workgroup
+k0, k1 = 2, max(k for k in range(15) if rt[:, k].all())
+dcy = ((ct[:, k1] - ct[:, k0]) & 0xffffffff).astype(np.float64); drt = ((rt[:, k1] - rt[:, k0]) & 0xffffffff).astype(np.float64)
+print(f"in-kernel clock over slots {k0}..{k1}: median {np.median(dcy / drt * 100):.0f} MHz (p10 {np.percentile(dcy / drt * 100, 10):.0f}, p90 {np.percentile(dcy / drt * 100, 90):.0f}), streams = {STREAMS}")
 print("cycle deltas (median):", [int(np.median(dc[:, k])) for k in range(11)])
 # who is late: the fourth tile's end (slot 12) by strip (x) and by vertical run (y) -- edge strips pad, runs differ in length by one tile
 if os.environ.get("STAMP_GRID"):
