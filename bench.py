@@ -345,7 +345,9 @@ def main():
             committed = {"source": "profiles/pmc_summary.json (builder's box, tools/profile_round.sh, 1 stream, one rocprofv3 --pmc pass per "
                                    "counter group)", "hbm_bytes_per_launch": prof.get("hbm_bytes_per_launch"),
                          "issue": {"valu_util": prof.get("valu_util"), "mfma_util": prof.get("mfma_util"),
-                                   "wait_inst_frac": prof.get("wait_inst_frac"), "lds_util": prof.get("lds_util")}}
+                                   "wait_inst_frac": prof.get("wait_inst_frac"), "lds_util": prof.get("lds_util"),
+                                   "inst_active_cycles_per_simd": prof.get("inst_active_cycles_per_simd"),
+                                   "in_kernel_clock_ghz": "1.75-1.95 under load, 2.39 idle (profiles/r04_h5_stamps.txt, r04_clock_under_load.txt)"}}
         roofline = {"bound": "hbm", "achieved": round(ach / 1e9, 2), "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                     "frac": round(ach / HBM_PEAK, 4), "traffic": None, "from_committed_profile": committed,
                     "kernel": f"launch{kdom}:layers{plan[kdom][0]}-{plan[kdom][0] + plan[kdom][1] - 1}:{names[plan[kdom][0]]}",

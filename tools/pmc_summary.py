@@ -49,6 +49,9 @@ for li, k in enumerate(kernels):
         ent["valu_util"] = round(c.get("SQ_ACTIVE_INST_VALU", 0) * 4 / N_SIMD / cyc, 3)
         ent["mfma_util"] = round(c.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) / N_SIMD / cyc, 3)
         ent["lds_util"] = round(c.get("SQ_LDS_IDX_ACTIVE", 0) / 256 / cyc, 3)
+        # cycles of instruction activity per SIMD (all of its waves, overlap counted twice): with the clock the chip holds under load
+        # (1.75-1.95 GHz in-kernel, tools/stamps.py; NOT 2.4) this is the kernel's instruction-bound time
+        ent["inst_active_cycles_per_simd"] = round(c.get("SQ_ACTIVE_INST_ANY", 0) * 4 / N_SIMD)
         if c.get("SQ_WAVE_CYCLES"):
             ent["wait_inst_frac"] = round(c.get("SQ_WAIT_INST_ANY", 0) / c["SQ_WAVE_CYCLES"], 3)      # issue stalls / wave-cycles
             ent["wait_any_frac"] = round(c.get("SQ_WAIT_ANY", 0) / c["SQ_WAVE_CYCLES"], 3)            # s_waitcnt + barriers
