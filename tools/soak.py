@@ -12,11 +12,13 @@ from sesrq import _lib
 from sesrq.bundle import Bundle
 rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 dev = torch.device("cuda:0")
-b = Bundle.load(os.path.join(ROOT, "tests/golden/sesr_x2_rand.crop.npz"))
+# SOAK_BUNDLE / SOAK_SHAPE / SOAK_GROUP: another net, frame size, frames per launch sequence (e.g. nrdm_3.crop.npz 3x540x960 8)
+b = Bundle.load(os.path.join(ROOT, "tests/golden", os.environ.get("SOAK_BUNDLE", "sesr_x2_rand.crop.npz")))
 e = sesrq.Engine(b, dev, engine=_lib.ENGINE_MFMA, wg_budget=512)
-S, F = 3, 24
+S, F, G = 3, 24, int(os.environ.get("SOAK_GROUP", "1"))
+shape = tuple(int(v) for v in os.environ.get("SOAK_SHAPE", "3x1080x1920").split("x"))
 g = torch.Generator(device="cpu").manual_seed(7)
-xs = [torch.rand((1, 3, 1080, 1920), generator=g).to(dev) for _ in range(F)]
+xs = [torch.rand((1,) + shape, generator=g).to(dev) for _ in range(F)]
 want = [e.forward(x, want_f=False)[0].clone() for x in xs]
 torch.cuda.synchronize()
 from oracle import sesrq_oracle as O, c_oracle as CO          # checker only
@@ -27,7 +29,7 @@ assert np.array_equal(ref, want[0].cpu().numpy()), "frame 0 differs from the C o
 print("frame 0 == C oracle", flush=True)
 streams = [torch.cuda.Stream(device=dev) for _ in range(S)]
 outs = [torch.zeros_like(want[0]) for _ in range(F)]
-sub = e.submission(xs, outs, streams)
+sub = e.submission(xs, outs, streams, group=G)
 bad = 0
 t0 = time.time()
 for r in range(rounds):
@@ -43,5 +45,5 @@ for r in range(rounds):
             print(f"round {r} frame {k}: {n} bytes differ", flush=True)
     if r % 10 == 9:
         print(f"round {r + 1}: {(r + 1) * F} frames compared, {bad} bad, {time.time() - t0:.0f} s", flush=True)
-print("SOAK", "FAILED" if bad else "ok", rounds * F, "frames")
+print("SOAK", "FAILED" if bad else "ok", rounds * F, "frames", b.name, shape, "group", G)
 sys.exit(1 if bad else 0)
