@@ -28,6 +28,7 @@ for p in (ROOT, os.path.join(ROOT, "sesr-pytorch-quantize_amd")):
         sys.path.insert(0, p)
 
 HBM_PEAK = 8.0e12            # B/s, MI355X HBM3E spec (/opt/skills/guides/MI355X_MICROARCH.md)
+MFMA_I8_PEAK = 5.0e15     # dense int8 MFMA, ops/s (MI355X_MICROARCH.md: twice the bf16 rate of ~2.5 PFLOP/s)
 POOL = 8                     # distinct resident input frames the steps rotate over
 
 # name: (nets [(bundle fixture, description)], Cin, H, W, frames: ("per_gpu", B) weak | ("total", B) strong, description)
@@ -352,8 +353,14 @@ def main():
                     "frac": round(ach / HBM_PEAK, 4), "traffic": None, "from_committed_profile": committed,
                     "kernel": f"launch{kdom}:layers{plan[kdom][0]}-{plan[kdom][0] + plan[kdom][1] - 1}:{names[plan[kdom][0]]}",
                     "kernel_ms": round(launch_ms[kdom], 5), "algorithmic_bytes_per_launch": alg[kdom],
+                    # int8_ops: 2 x the layers' real multiply-accumulates (K x K x Cin x Cout per pixel, no padding); mfma_frac against the dense
+                    # int8 MFMA peak (MI355X_MICROARCH.md: 2 x the bf16 rate, ~5 POP/s at 2.4 GHz) -- the kernels are nearer the HBM roofline
+                    # than this one, hence bound = "hbm"
                     "launches": [{"layers": [f, f + c - 1], "kernel": names[f], "ms": round(launch_ms[j], 5), "alg_bytes": alg[j],
-                                  "frac": round(alg[j] / (launch_ms[j] * 1e-3) / HBM_PEAK, 4)} for j, (f, c) in enumerate(plan)],
+                                  "frac": round(alg[j] / (launch_ms[j] * 1e-3) / HBM_PEAK, 4),
+                                  "int8_ops": int(2 * px * sum(int(np.prod(bundle.layers[k].wq.shape)) for k in range(f, f + c))),
+                                  "mfma_frac": round(2 * px * sum(int(np.prod(bundle.layers[k].wq.shape)) for k in range(f, f + c))
+                                                     / (launch_ms[j] * 1e-3) / MFMA_I8_PEAK, 4)} for j, (f, c) in enumerate(plan)],
                     "forward_device_ms": round(fwd_ms, 5),
                     "bytes_per_frame": {"as_launched": per_frame_fused, "layer_by_layer": per_frame_layerwise},
                     "throughput_frac": round(per_frame_fused * fps / world / HBM_PEAK, 4),
