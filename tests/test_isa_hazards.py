@@ -21,6 +21,7 @@ def test_no_valu_write_behind_a_wide_store(stem, tmp_path):
     # the library's own flags (one source of truth: the Makefile), device side only, assembly out
     flags = subprocess.run(["make", "-s", "-C", CSRC, "print-cxxflags"], check=True, capture_output=True, text=True).stdout.split()
     assert "-ffp-contract=off" in flags and "-fPIC" in flags
+    flags += subprocess.run(["make", "-s", "-C", CSRC, "print-fileflags-" + stem], check=True, capture_output=True, text=True).stdout.split()
     flags += ["-I" + CSRC, "--cuda-device-only", "-S"]
     subprocess.run([HIPCC] + flags + [os.path.join(CSRC, stem + ".hip"), "-o", asm], check=True, capture_output=True)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "store_hazard_scan.py"), asm], capture_output=True, text=True)

@@ -9,7 +9,7 @@ FILES=${@:-sesrq_mfma sesrq_trio}
 mkdir -p $OUT
 FLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -fno-fast-math -mllvm -amdgpu-mfma-vgpr-form -I$ROOT/include -Wall -Wno-unused-result"
 pids=()
-for f in $FILES; do /opt/rocm/bin/hipcc $FLAGS $EXTRA -c $SRC/$f.hip -o $OUT/$f.o & pids+=($!); done
+for f in $FILES; do /opt/rocm/bin/hipcc $FLAGS $(make -s -C $SRC print-fileflags-$f) $EXTRA -c $SRC/$f.hip -o $OUT/$f.o & pids+=($!); done      # the library's per-file flags first: EXTRA can override them
 for p in "${pids[@]}"; do wait $p; done
 OBJS=""
 for f in sesrq_api sesrq_dot4 sesrq_mfma sesrq_trio sesrq_quad sesrq_verify sesrq_calib; do
