@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define SESRQ_VERSION 3
+#define SESRQ_VERSION 4
 #define SESRQ_MAX_LAYERS 16
 #define SESRQ_MAX_CH 16
 
@@ -62,6 +62,16 @@ typedef struct sesrq_options {
                               * bit-identical to handing the upstream net's fp32 output over (the float hand-off between chained
                               * nets) at a quarter of the bytes */
     int32_t i8_in_zero;
+    int32_t reduced_forms;   /* bit mask of the PROVEN reduced epilogue forms the kernels may select (round 5; no reference counterpart: every form
+                              * gives the reference's bits, the mask only chooses which kernel instantiation computes them -- it exists so that
+                              * tests can run EVERY instantiation on reference-made data).  -1 (default) = all; the environment variable
+                              * SESRQ_DIRECT=0 turns the default into 1 | 8.
+                              *   1: fused trio: cvt_pk_u8 epilogues where every zero point involved is -128
+                              *   2: one-fma requant (sesrq_layer_one_fma == 1) in the first layer and in layers a, b of a fused trio
+                              *   4: ... in the third layer of a fused trio
+                              *   8: fused trio: the residual operand out of the LDS input window where it is the trio's input tensor
+                              *  16: output layer: one-fma form 1        32: output layer: single-rounding form 2 (tried when form 1 is
+                              *      not proven or not allowed) */
 } sesrq_options;
 void sesrq_default_options(sesrq_options *opts);
 
@@ -146,19 +156,32 @@ int sesrq_forward(const sesrq_net *net, const void *in, int in_dtype, void *out_
  * reference has no counterpart (it is batch-1, quan_func.py:349, 373); per frame the bytes are sesrq_forward's.  Every frames[k].in is an
  * (N, Cin, H, W) buffer of in_dtype, out_q / out_f as in sesrq_forward (either may be NULL, not both).  Caller-owned buffers, no
  * allocation, no synchronisation.  Returns non-zero at the first frame that fails (earlier frames stay enqueued).
- * Grouping: with N == 1 and a workspace of sesrq_workspace_bytes(net, G, H, W) bytes, G <= 8, up to G consecutive frames of a stream
- * become the G images of ONE launch sequence (their buffers stay where they are: a pointer table in the kernel arguments of the first and
- * the last layer) -- the same kernels and bytes, the launches' fixed cost once per group.  A workspace for one frame keeps one launch
- * sequence per frame.  Frames that may share a launch sequence (any G consecutive frames of a stream) must not share an output buffer.
+ * Grouping (`group` = G, explicit since ABI v4 -- v3 inferred it from the workspace size, which turned a generously sized workspace into a
+ * silent write race for callers that re-use one output buffer per stream): G = 1 keeps one launch sequence per frame.  G in 2..8 needs
+ * N == 1, the MFMA first- and last-layer kernels (every reference net on the default engine) and workspaces of
+ * sesrq_workspace_bytes(net, G, H, W) bytes; up to G consecutive frames of a stream then become the G images of ONE launch sequence
+ * (their buffers stay where they are: a pointer table in the kernel arguments of the first and the last layer) -- the same kernels and
+ * bytes, the launches' fixed cost once per group.  The frames of one group are written concurrently: two of them sharing an out_q or
+ * out_f buffer is refused (error return, nothing of that group enqueued).
  * Threads: every stream's frames are enqueued by a persistent library thread of its own, in order (SESRQ_SUBMIT_THREADS=0: by the
- * caller's thread); a second sesrq_forward_many that arrives while one is running enqueues on its caller's thread. */
+ * caller's thread); a second sesrq_forward_many that arrives while one is running enqueues on its caller's thread.  A worker spins on
+ * its job slot for SESRQ_SPIN_US microseconds (default 2000; 0 = sleep at once) after a batch before it sleeps on a condition variable:
+ * with S streams that is up to S - 1 busy host cores between closely spaced batches -- set it to 0 where ranks outnumber a quarter of
+ * the cores (bench.py does).  The pool is per process: a fork()ed child gets a fresh one on its first call (pthread_atfork), the
+ * parent's threads are never touched from the child.  A job a worker does not pick up within 200 ms is taken back and run by the
+ * caller; a worker that holds a job for more than 60 s makes the call return an error. */
 typedef struct sesrq_frame_io {
     const void *in;
     void *out_q;
     void *out_f;
 } sesrq_frame_io;
 int sesrq_forward_many(const sesrq_net *net, const sesrq_frame_io *frames, int count, int in_dtype, int N, int H, int W,
-                       void *const *workspaces, size_t workspace_bytes, void *const *streams, int n_streams);
+                       void *const *workspaces, size_t workspace_bytes, void *const *streams, int n_streams, int group);
+
+/* Self-test of the submission pool without a net or a device (tests/test_host_abi.py: a fork()ed child must get a working pool of its
+ * own): `rounds` times, n_streams trivial jobs go through exactly the hand-off sesrq_forward_many uses (job 0 on the caller's thread, the
+ * others on the pool's threads).  Returns the number of jobs that ran (n_streams * rounds) or -1. */
+int sesrq_submit_selftest(int n_streams, int rounds);
 
 /* Debug taps mirroring the reference's dump flags (define.py:23-31).  After a forward run
  * with sesrq_forward_debug, stage tensors are written to caller buffers (device pointers, any
@@ -179,6 +202,11 @@ typedef struct sesrq_taps {
      * [k][1] = below it, BEFORE saturation -- the events the reference reports as 'max_overflow' /
      * 'min_overflow' (myQL/quan_func.py:358-361) and then saturates silently, as this library does. */
     void *overflow;
+    /* round 5: the two tensors the reference writes besides (both optional; either takes its layer to the dot4 kernels)
+     *   shortcut : (N, OC_0, H, W) fp32  residual/shortcut_tensor.pt = relu(acc * M * 2^-n) of layer 0, un-rounded (myQL/quan_func.py:529-549)
+     *   ic       : (N, OC_{L-2}, H, W) int8  input.4.spcial.pt = clamp8(rint(relu(t) - 128)) of layer L-2 (myQL/quan_func.py:250,254) */
+    void *shortcut;
+    void *ic;
 } sesrq_taps;
 int sesrq_forward_debug(const sesrq_net *net, const void *in, int in_dtype, void *out_q, void *out_f,
                         int N, int H, int W, void *workspace, size_t workspace_bytes, void *stream,
@@ -197,6 +225,14 @@ int sesrq_launch_plan(const sesrq_net *net, int *first, int *count);
 int sesrq_forward_timed(const sesrq_net *net, const void *in, int in_dtype, void *out_q, void *out_f,
                         int N, int H, int W, void *workspace, size_t workspace_bytes, void *stream,
                         int iters, float *launch_ms, float *forward_ms);
+
+/* Every kernel instantiation the library can launch, by construction (csrc/sesrq_common.h: launch_kernel<KERN> registers KERN when the
+ * library is loaded), with the name a rocprofv3 kernel trace prints for it ("mfma_h5_kernel<1, 2, 22, 3>") and the number of launches
+ * of it by this process so far -- so that a test can prove that it has run every instantiation (tests/test_gpu_parity.py:
+ * test_every_kernel_instance_runs_on_reference_data).  No reference counterpart. */
+int sesrq_instance_count(void);
+const char *sesrq_instance_name(int i);
+long long sesrq_instance_launches(int i);
 
 /* Name of the kernel the net resolved to for layer k ("dot4-general", "mfma-h3-merged", "mfma-trio-merged", ...). */
 const char *sesrq_layer_engine(const sesrq_net *net, int k);

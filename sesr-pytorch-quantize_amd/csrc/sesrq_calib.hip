@@ -133,8 +133,8 @@ int sesrq_calib_minmax(const float *x, size_t n, float *out_min_max, void *scrat
     static const unsigned init[2] = {0xffffffffu, 0u};
     if (hipMemcpyAsync(scratch8, init, sizeof(init), hipMemcpyHostToDevice, st) != hipSuccess) { set_error("sesrq_calib_minmax: memcpy failed"); return 1; }
     const int blocks = (int)std::min<size_t>((n + 255) / 256, 2048);
-    hipLaunchKernelGGL(calib_minmax_kernel, dim3(blocks), dim3(256), 0, st, x, n, (unsigned *)scratch8);
-    hipLaunchKernelGGL(calib_minmax_finish, dim3(1), dim3(1), 0, st, (const unsigned *)scratch8, out_min_max);
+    launch_kernel<calib_minmax_kernel>(dim3(blocks), dim3(256), 0, st, x, n, (unsigned *)scratch8);
+    launch_kernel<calib_minmax_finish>(dim3(1), dim3(1), 0, st, (const unsigned *)scratch8, out_min_max);
     return hipGetLastError() == hipSuccess ? 0 : 1;
 }
 
@@ -148,8 +148,8 @@ int sesrq_calib_conv(const sesrq_calib_conv_desc *d, const float *in, const floa
     a.scale = d->in_scale; a.zero = (float)d->in_zero; a.ss = d->ss;
     a.acc_lo = d->acc_lo; a.acc_hi = d->acc_hi; a.add_lo = d->add_lo; a.add_hi = d->add_hi; a.relu = d->relu;
     dim3 grid((W + 31) / 32, (H + 7) / 8, N);
-    if (d->k == 3) hipLaunchKernelGGL(calib_conv_kernel<3>, grid, dim3(256), 0, (hipStream_t)stream, a);
-    else hipLaunchKernelGGL(calib_conv_kernel<5>, grid, dim3(256), 0, (hipStream_t)stream, a);
+    if (d->k == 3) launch_kernel<calib_conv_kernel<3>>(grid, dim3(256), 0, (hipStream_t)stream, a);
+    else launch_kernel<calib_conv_kernel<5>>(grid, dim3(256), 0, (hipStream_t)stream, a);
     if (hipGetLastError() != hipSuccess) { set_error("sesrq_calib_conv: launch failed"); return 1; }
     return 0;
 }
@@ -160,14 +160,14 @@ int sesrq_calib_histogram(const float *x, size_t n, float lo, float hi, int bins
     if (!(hi > lo) || !std::isfinite(lo) || !std::isfinite(hi)) { set_error("sesrq_calib_histogram: need finite lo < hi"); return 1; }
     const float inv_w = (float)bins / (hi - lo);
     const int blocks = (int)std::min<size_t>((n + 256 * 16 - 1) / (256 * 16), 2048);
-    hipLaunchKernelGGL(calib_hist_kernel, dim3(std::max(blocks, 1)), dim3(256), 0, (hipStream_t)stream, x, n, lo, inv_w, bins, (unsigned *)hist);
+    launch_kernel<calib_hist_kernel>(dim3(std::max(blocks, 1)), dim3(256), 0, (hipStream_t)stream, x, n, lo, inv_w, bins, (unsigned *)hist);
     if (hipGetLastError() != hipSuccess) { set_error("sesrq_calib_histogram: launch failed"); return 1; }
     return 0;
 }
 
 int sesrq_calib_fakequant(const float *in, float *out, size_t n, float scale, int zero, void *stream) {
     if (!in || !out || n == 0 || !(scale > 0.f)) { set_error("sesrq_calib_fakequant: bad argument"); return 1; }
-    hipLaunchKernelGGL(calib_fakequant_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, in, out, n, scale, (float)zero);
+    launch_kernel<calib_fakequant_kernel>(dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, in, out, n, scale, (float)zero);
     return hipGetLastError() == hipSuccess ? 0 : 1;
 }
 

@@ -16,10 +16,27 @@ namespace sesrq {
 // reports) instead of a hipEventRecord pair around it, which would add the dispatch latency of the launch to every interval.
 struct KernelEvents { hipEvent_t start = nullptr, stop = nullptr; };
 extern thread_local KernelEvents tl_kernel_events;
-template <typename K, typename A>
-inline void launch_kernel(K kern, dim3 grid, dim3 block, unsigned lds, hipStream_t st, const A &a) {
-    if (tl_kernel_events.start) hipExtLaunchKernelGGL(kern, grid, block, lds, st, tl_kernel_events.start, tl_kernel_events.stop, 0, a);
-    else hipLaunchKernelGGL(kern, grid, block, lds, st, a);
+// Registry of the kernel instantiations the library can select (round 5).  EVERY launch of the library goes through launch_kernel<KERN>:
+// instantiating that template for a kernel odr-uses KernelInstance<KERN>::id, whose dynamic initialiser registers the kernel's name when
+// the library is loaded -- so the table is complete by construction: a kernel that can be launched is in it, whether or not any test has
+// reached it yet.  sesrq_instance_count / _name / _launches (include/sesrq.h) expose the table and a per-process launch counter;
+// tests/test_gpu_parity.py:test_every_kernel_instance_runs_on_reference_data fails for an instantiation no case of its matrix launched.
+// (Round 4 shipped 9.5 M wrong bytes in an instantiation -- the int8-only last layer -- that 168 green tests never selected.)
+int register_instance(const void *host_fn, const char *pretty_function);
+void count_launch(int id);
+template <auto KERN>
+struct KernelInstance {
+    static const char *pretty() { return __PRETTY_FUNCTION__; }      // "... [KERN = &sesrq::mfma_h5_kernel<1, 2, 22, 3>]"
+    static const int id;
+};
+template <auto KERN>
+const int KernelInstance<KERN>::id = register_instance((const void *)KERN, KernelInstance<KERN>::pretty());
+
+template <auto KERN, typename... A>
+inline void launch_kernel(dim3 grid, dim3 block, unsigned lds, hipStream_t st, const A &...a) {
+    count_launch(KernelInstance<KERN>::id);
+    if (tl_kernel_events.start) hipExtLaunchKernelGGL(KERN, grid, block, lds, st, tl_kernel_events.start, tl_kernel_events.stop, 0, a...);
+    else hipLaunchKernelGGL(KERN, grid, block, lds, st, a...);
 }
 
 // Compute units of the CURRENT device, cached per device id (a process may hold nets on several devices: net->device).
@@ -147,6 +164,8 @@ struct ConvArgs {
     int *dbg_pe;             // (N,4,OC,H,W) int32 or NULL
     int *dbg_add;            // (N,OC,H,W) int32 or NULL
     signed char *dbg_q0;     // (N,IC,H,W) int8: quantised input of layer 0 or NULL (dot4 kernels only)
+    float *dbg_t;            // (N,OC,H,W) fp32: the layer's un-rounded requant output after its activation (layer 0: shortcut_tensor.pt), or NULL (dot4 kernels only)
+    signed char *dbg_ic;     // (N,OC,H,W) int8: EPI_PRERES: ic = clamp8(rint(t - 128)) (input.4.spcial.pt), or NULL (dot4 kernels only)
     int *dbg_ovf;            // [2] counters: PE sums above / below the accumulator range before saturation, or NULL (dot4 general kernels only)
     int N, H, W;
     int chunk_tiles;         // mfma engine: vertically adjacent tiles walked by one workgroup
@@ -188,6 +207,7 @@ struct TrioArgs {
     int chunk_steps;         // 8-row steps per run, rounded up
     int run_unit;            // trio: rows per partition unit of the vertical runs, 8 (whole steps) or 4 (half steps)
     int wg_budget;           // workgroup slots the launch may fill (0 = one round of the chip)
+    int allow;               // sesrq_options.reduced_forms: which proven reduced forms the launch may select (bits 1, 2, 4, 8)
     int pad_in;              // pad word of the first layer's input
     float Mres, shres, z_merge;
     const int *merge_lut;    // 128 dwords = 512 bytes: q4 as a function of u = (rc + 128) + (ic + 128), the residual merge's second requant (sesrq_create)
@@ -216,6 +236,21 @@ struct LayerPlan {
 
 void set_error(const std::string &msg);
 
+// load-time proof (sesrq_verify.hip): can the 18-bit PE clamp / 20-bit adder clamp of this layer ever fire?
+bool saturation_free(const sesrq_layer_desc &d, int zc, int acc_bits, int add_bits, long long &worst_pe, long long &worst_sum, int &risky_mask,
+                     int *risky_oc = nullptr);
+
+// launch planner (sesrq_plan.hip)
+struct WsLayout {
+    size_t act_bytes;      // one NHWC16 activation tensor
+    size_t off_s, off_a, off_b, off_rc, total;
+};
+WsLayout ws_layout(const sesrq_net *net, int N, int H, int W);
+bool groupable(const sesrq_net *net);      // can frames of separate caller buffers be the images of one launch (ConvArgs::ft)?
+// ft != NULL: the launch's N = ft->n images are the frames ft->in[k] -> ft->out_q[k] / ft->out_f[k]
+int forward_impl(const sesrq_net *net, const void *in, int in_dtype, void *out_q, void *out_f, int N, int H, int W, void *workspace,
+                 size_t workspace_bytes, void *stream, const sesrq_taps *taps, hipEvent_t *ev, const FrameTable *ft = nullptr);
+
 // dot4 engine
 int launch_dot4(const LayerPlan &lp, bool general, const ConvArgs &a, int src, int epi, hipStream_t st);      // general: per-PE sums + clamps
 // mfma engine
@@ -240,6 +275,7 @@ struct sesrq_net {
     int anchor_add = 0;
     int fuse_hidden = 1;
     int wg_budget = 0;
+    int reduced_forms = -1;             // sesrq_options.reduced_forms, resolved (never -1 after sesrq_create)
     float i8_in_scale = 0.f;            // > 0: int8 input frames are in this (scale, zero) domain of an upstream net
     int i8_in_zero = 0;
     int *d_merge_lut = nullptr;         // device: 512-byte table of the residual merge (see TrioArgs::merge_lut)

@@ -154,6 +154,7 @@ __global__ __launch_bounds__(256) void conv_dot4_kernel(const ConvArgs a) {
         float v = __fmul_rn((float)s, a.Mf) * a.sh;
         if (a.relu) v = fmaxf(v, 0.f);
         t[o] = v;
+        if (a.dbg_t && o < a.oc) a.dbg_t[((size_t)n * a.oc + o) * HW + (size_t)gy * W + gx] = v;      // layer 0: shortcut_tensor.pt (quan_func.py:529-549)
     }
 
     if constexpr (GENERAL) {
@@ -178,6 +179,7 @@ __global__ __launch_bounds__(256) void conv_dot4_kernel(const ConvArgs a) {
             if constexpr (EPI == EPI_PRERES) {
                 const float rc = (float)(signed char)((rcw[p] >> (8 * j)) & 0xff);
                 const float ic = q8f(__fadd_rn(t[o], -128.f));
+                if (a.dbg_ic && o < a.oc) a.dbg_ic[((size_t)n * a.oc + o) * HW + (size_t)gy * W + gx] = (signed char)(int)ic;      // input.4.spcial.pt (quan_func.py:250,254)
                 const float u = rc + ic + 256.f;
                 const float v = __fmul_rn(u, a.Mres) * a.shres;
                 q = q8f(__fadd_rn(v, a.z_merge));
@@ -226,15 +228,14 @@ __global__ void unpack_nhwc16_kernel(const int4 *__restrict__ in, signed char *_
 
 int launch_unpack_nhwc16(const void *nhwc, signed char *nchw, int N, int C, int H, int W, hipStream_t st) {
     const size_t HW = (size_t)H * W, total = HW * N;
-    hipLaunchKernelGGL(unpack_nhwc16_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st,
-                       reinterpret_cast<const int4 *>(nhwc), nchw, C, HW, total);
+    launch_kernel<unpack_nhwc16_kernel>(dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, reinterpret_cast<const int4 *>(nhwc), nchw, C, HW, total);
     return hipGetLastError() == hipSuccess ? 0 : 1;
 }
 
 template <int K, int IN_DW, bool GENERAL, int EPI, int OCP, int SRC>
 static void launch_one(const ConvArgs &a, hipStream_t st) {
     dim3 grid((a.W + TW - 1) / TW, (a.H + TH - 1) / TH, a.N);
-    launch_kernel(conv_dot4_kernel<K, IN_DW, GENERAL, EPI, OCP, SRC>, grid, dim3(256), 0, st, a);
+    launch_kernel<conv_dot4_kernel<K, IN_DW, GENERAL, EPI, OCP, SRC>>(grid, dim3(256), 0, st, a);
 }
 
 template <int K, bool GENERAL>

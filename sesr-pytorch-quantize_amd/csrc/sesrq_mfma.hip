@@ -996,8 +996,9 @@ extern "C" int sesrq_debug_fetch_stamps(void *host, size_t bytes) {
 // co-resident workgroups per CU comes from the occupancy API for THIS kernel (registers / LDS differ a
 // lot between the merged and general variants); a strip's row tiles are then cut into the largest
 // number of equal vertical runs that still fits.
-template <typename K>
-static void launch(K kern, ConvArgs a, hipStream_t st, int tile_h = MTH) {
+template <auto KERN>
+static void launch(ConvArgs a, hipStream_t st, int tile_h = MTH) {
+    const auto kern = KERN;
     static std::mutex mu;
     static std::map<const void *, int> occ;          // per kernel (all instantiations share this function type)
     const int num_cu = device_cu_count();
@@ -1017,7 +1018,7 @@ static void launch(K kern, ConvArgs a, hipStream_t st, int tile_h = MTH) {
     k = std::max(1LL, std::min<long long>(k, row_tiles));
     a.chunk_tiles = (int)((row_tiles + k - 1) / k);
     dim3 grid(strips, (int)k, a.N);
-    launch_kernel(kern, grid, dim3(256), 0, st, a);
+    launch_kernel<KERN>(grid, dim3(256), 0, st, a);
 }
 
 // hybrid first layer on the sparse MFMA, by the register that needs the clamp (3 input channels only: a.afrag_sp is set for nothing else)
@@ -1025,30 +1026,30 @@ template <int SRC, bool RC, int NCH>
 static void launch_f5_sparse(const ConvArgs &a, hipStream_t st) {
     if constexpr (NCH == 3) {
         switch (a.risky_reg) {
-            case 0: launch(mfma_f5_kernel_w4<HYBS, SRC, RC, 3, 0>, a, st, F5_TH); break;
-            case 1: launch(mfma_f5_kernel_w4<HYBS, SRC, RC, 3, 1>, a, st, F5_TH); break;
-            case 2: launch(mfma_f5_kernel_w4<HYBS, SRC, RC, 3, 2>, a, st, F5_TH); break;
-            case 3: launch(mfma_f5_kernel_w4<HYBS, SRC, RC, 3, 3>, a, st, F5_TH); break;
-            default: launch(mfma_f5_kernel_w4<HYBS, SRC, RC, 3, 4>, a, st, F5_TH); break;
+            case 0: launch<mfma_f5_kernel_w4<HYBS, SRC, RC, 3, 0>>(a, st, F5_TH); break;
+            case 1: launch<mfma_f5_kernel_w4<HYBS, SRC, RC, 3, 1>>(a, st, F5_TH); break;
+            case 2: launch<mfma_f5_kernel_w4<HYBS, SRC, RC, 3, 2>>(a, st, F5_TH); break;
+            case 3: launch<mfma_f5_kernel_w4<HYBS, SRC, RC, 3, 3>>(a, st, F5_TH); break;
+            default: launch<mfma_f5_kernel_w4<HYBS, SRC, RC, 3, 4>>(a, st, F5_TH); break;
         }
     } else {
-        launch(mfma_f5_kernel_w4<HYB, SRC, RC, NCH>, a, st, F5_TH);
+        launch<mfma_f5_kernel_w4<HYB, SRC, RC, NCH>>(a, st, F5_TH);
     }
 }
 
 #define SESRQ_BY_MODE(KERN, ...)                                                         \
     do {                                                                                 \
-        if (mode == MERGED) launch(KERN<MERGED, __VA_ARGS__>, a, st);                    \
-        else if (mode == GEN_STD) launch(KERN<GEN_STD, __VA_ARGS__>, a, st);             \
-        else if (mode == HYB) launch(KERN<HYB, __VA_ARGS__>, a, st);                     \
-        else launch(KERN<GEN_ANY, __VA_ARGS__>, a, st);                                  \
+        if (mode == MERGED) launch<KERN<MERGED, __VA_ARGS__>>(a, st);                    \
+        else if (mode == GEN_STD) launch<KERN<GEN_STD, __VA_ARGS__>>(a, st);             \
+        else if (mode == HYB) launch<KERN<HYB, __VA_ARGS__>>(a, st);                     \
+        else launch<KERN<GEN_ANY, __VA_ARGS__>>(a, st);                                  \
     } while (0)
 // the one-fma last-layer flavours exist for the biased modes only (GEN_ANY sums carry no bias: it keeps the general store)
 #define SESRQ_BY_MODE_B(KERN, ...)                                                       \
     do {                                                                                 \
-        if (mode == MERGED) launch(KERN<MERGED, __VA_ARGS__>, a, st);                    \
-        else if (mode == GEN_STD) launch(KERN<GEN_STD, __VA_ARGS__>, a, st);             \
-        else launch(KERN<HYB, __VA_ARGS__>, a, st);                                      \
+        if (mode == MERGED) launch<KERN<MERGED, __VA_ARGS__>>(a, st);                    \
+        else if (mode == GEN_STD) launch<KERN<GEN_STD, __VA_ARGS__>>(a, st);             \
+        else launch<KERN<HYB, __VA_ARGS__>>(a, st);                                      \
     } while (0)
 
 int launch_mfma(const LayerPlan &lp, const ConvArgs &a_in, int src, int epi, bool general, hipStream_t st, bool one_risky_pe, bool tap) {
@@ -1064,20 +1065,20 @@ int launch_mfma(const LayerPlan &lp, const ConvArgs &a_in, int src, int epi, boo
         if (lp.d_afrag_pesplit && a.afrag == lp.d_afrag_pesplit) { set_error("mfma: the pe-split last-layer kernel has no PE taps"); return 1; }
         switch (lp.mfma_kind) {
             case MFMA_H3:
-                if (epi == EPI_MID) launch(mfma_h3_kernel<GEN_TAP, EPI_MID>, a, st);
-                else if (epi == EPI_PRERES) launch(mfma_h3_kernel<GEN_TAP, EPI_PRERES>, a, st);
+                if (epi == EPI_MID) launch<mfma_h3_kernel<GEN_TAP, EPI_MID>>(a, st);
+                else if (epi == EPI_PRERES) launch<mfma_h3_kernel<GEN_TAP, EPI_PRERES>>(a, st);
                 else { set_error("mfma: 3x3 last layer not supported"); return 1; }
                 break;
             case MFMA_H5:
-                if (epi == EPI_MID) launch(mfma_h5_kernel<GEN_TAP, EPI_MID>, a, st);
-                else if (epi == EPI_PRERES) launch(mfma_h5_kernel<GEN_TAP, EPI_PRERES>, a, st);
-                else if (last_nv(a.oc) == 3) launch(mfma_h5_kernel<GEN_TAP, EPI_LAST, 0, 3>, a, st);
-                else launch(mfma_h5_kernel<GEN_TAP, EPI_LAST>, a, st);
+                if (epi == EPI_MID) launch<mfma_h5_kernel<GEN_TAP, EPI_MID>>(a, st);
+                else if (epi == EPI_PRERES) launch<mfma_h5_kernel<GEN_TAP, EPI_PRERES>>(a, st);
+                else if (last_nv(a.oc) == 3) launch<mfma_h5_kernel<GEN_TAP, EPI_LAST, 0, 3>>(a, st);
+                else launch<mfma_h5_kernel<GEN_TAP, EPI_LAST>>(a, st);
                 break;
             case MFMA_F5:
-                if (src == SRC_F32) { if (a.rc_out) launch(mfma_f5_kernel<GEN_TAP, SRC_F32, true, 4>, a, st, F5_TH); else launch(mfma_f5_kernel<GEN_TAP, SRC_F32, false, 4>, a, st, F5_TH); }
-                else if (src == SRC_I8D) { if (a.rc_out) launch(mfma_f5_kernel<GEN_TAP, SRC_I8D, true, 4>, a, st, F5_TH); else launch(mfma_f5_kernel<GEN_TAP, SRC_I8D, false, 4>, a, st, F5_TH); }
-                else { if (a.rc_out) launch(mfma_f5_kernel<GEN_TAP, SRC_I8, true, 4>, a, st, F5_TH); else launch(mfma_f5_kernel<GEN_TAP, SRC_I8, false, 4>, a, st, F5_TH); }
+                if (src == SRC_F32) { if (a.rc_out) launch<mfma_f5_kernel<GEN_TAP, SRC_F32, true, 4>>(a, st, F5_TH); else launch<mfma_f5_kernel<GEN_TAP, SRC_F32, false, 4>>(a, st, F5_TH); }
+                else if (src == SRC_I8D) { if (a.rc_out) launch<mfma_f5_kernel<GEN_TAP, SRC_I8D, true, 4>>(a, st, F5_TH); else launch<mfma_f5_kernel<GEN_TAP, SRC_I8D, false, 4>>(a, st, F5_TH); }
+                else { if (a.rc_out) launch<mfma_f5_kernel<GEN_TAP, SRC_I8, true, 4>>(a, st, F5_TH); else launch<mfma_f5_kernel<GEN_TAP, SRC_I8, false, 4>>(a, st, F5_TH); }
                 break;
             default: set_error("mfma: layer shape not supported by the MFMA engine"); return 1;
         }
@@ -1095,9 +1096,9 @@ int launch_mfma(const LayerPlan &lp, const ConvArgs &a_in, int src, int epi, boo
             break;
         case MFMA_H5:
             if (epi == EPI_LAST && lp.d_afrag_pesplit && a.afrag == lp.d_afrag_pesplit) {
-                if (mode == MERGED) launch(mfma_h5p_kernel<MERGED>, a, st);
-                else if (mode == GEN_ANY) launch(mfma_h5p_kernel<GEN_ANY>, a, st);
-                else launch(mfma_h5p_kernel<GEN_STD>, a, st);
+                if (mode == MERGED) launch<mfma_h5p_kernel<MERGED>>(a, st);
+                else if (mode == GEN_ANY) launch<mfma_h5p_kernel<GEN_ANY>>(a, st);
+                else launch<mfma_h5p_kernel<GEN_STD>>(a, st);
                 break;
             }
             if (epi == EPI_MID) SESRQ_BY_MODE(mfma_h5_kernel, EPI_MID);
@@ -1115,11 +1116,11 @@ int launch_mfma(const LayerPlan &lp, const ConvArgs &a_in, int src, int epi, boo
         case MFMA_F5:
 #define SESRQ_F5(...)                                                                    \
     do {                                                                                 \
-        if (mode == MERGED) launch(mfma_f5_kernel_w4<MERGED, __VA_ARGS__>, a, st, F5_TH);       \
+        if (mode == MERGED) launch<mfma_f5_kernel_w4<MERGED, __VA_ARGS__>>(a, st, F5_TH);       \
         else if (mode == HYB && a.afrag_sp) launch_f5_sparse<__VA_ARGS__>(a, st);        \
-        else if (mode == HYB) launch(mfma_f5_kernel_w4<HYB, __VA_ARGS__>, a, st, F5_TH);        \
-        else if (mode == GEN_STD) launch(mfma_f5_kernel<GEN_STD, __VA_ARGS__>, a, st, F5_TH);   \
-        else launch(mfma_f5_kernel<GEN_ANY, __VA_ARGS__>, a, st, F5_TH);                        \
+        else if (mode == HYB) launch<mfma_f5_kernel_w4<HYB, __VA_ARGS__>>(a, st, F5_TH);        \
+        else if (mode == GEN_STD) launch<mfma_f5_kernel<GEN_STD, __VA_ARGS__>>(a, st, F5_TH);   \
+        else launch<mfma_f5_kernel<GEN_ANY, __VA_ARGS__>>(a, st, F5_TH);                        \
     } while (0)
 #define SESRQ_F5_NCH(...)                                                      \
     do {                                                                       \

@@ -359,8 +359,8 @@ __global__ __launch_bounds__(256) void mfma_trio_kernel(const TrioArgs a) {
 // one workgroup more than its neighbours sets the kernel time while the others idle (measured: 864 workgroups on 1024 slots,
 // SQ busy 1.47 x the average wave lifetime).  The dynamic LDS size is padded so that exactly `occ` workgroups fit a CU, and a
 // strip is cut into floor(occ * CUs / (strips * N)) runs whose lengths differ by at most one step.
-template <typename K>
-static void launch_trio_k(K kern, TrioArgs a, hipStream_t st) {
+template <auto KERN>
+static void launch_trio_k(TrioArgs a, hipStream_t st) {
     // 4 workgroups per CU: the LDS size a plain launch accepts and the kernel's registers allow (3 and 5 measured slower, rounds 2-3)
     constexpr int occ = 4;
     const int num_cu = device_cu_count();
@@ -371,7 +371,7 @@ static void launch_trio_k(K kern, TrioArgs a, hipStream_t st) {
     a.chunk_steps = (int)((steps + k - 1) / k);
     a.run_unit = (steps < 3 * k) ? TH / 2 : TH;                           // short runs (< 3 steps) are cut in half-step units
     dim3 grid(strips, (int)k, a.N);
-    launch_kernel(kern, grid, dim3(256), (unsigned)lds, st, a);
+    launch_kernel<KERN>(grid, dim3(256), (unsigned)lds, st, a);
 }
 
 #ifdef SESRQ_STAMPS
@@ -386,19 +386,22 @@ int launch_trio(const TrioArgs &a, int epi_c, hipStream_t st) {
     bool u8 = a.l[0].z_next == -128.f && a.l[1].z_next == -128.f && a.l[0].zlo == -128.f && a.l[1].zlo == -128.f;
     if (epi_c == EPI_PRERES) u8 = u8 && a.z_merge == -128.f;
     else u8 = u8 && a.l[2].z_next == -128.f && a.l[2].zlo == -128.f;
-    const bool ab = u8 && a.l[0].direct && a.l[1].direct, abc = ab && a.l[2].direct;      // one-fma requants (proof per layer)
+    // sesrq_options.reduced_forms (TrioArgs::allow): 1 = the cvt_pk_u8 epilogues, 2 = one-fma requants of layers a and b, 4 = of the third
+    // layer, 8 = the residual operand out of the input window -- each only where its proof / precondition holds
+    u8 = u8 && (a.allow & 1);
+    const bool ab = u8 && (a.allow & 2) && a.l[0].direct && a.l[1].direct, abc = ab && (a.allow & 4) && a.l[2].direct;      // one-fma requants (proof per layer)
     const int mode = abc ? 7 : (ab ? 3 : (u8 ? 1 : 0));
     if (epi_c == EPI_PRERES) {
-        if (mode == 7 && a.rc_in == a.in) launch_trio_k(mfma_trio_kernel<EPI_PRERES, 15>, a, st);      // the residual operand out of the input window
-        else if (mode == 7) launch_trio_k(mfma_trio_kernel<EPI_PRERES, 7>, a, st);
-        else if (mode == 3) launch_trio_k(mfma_trio_kernel<EPI_PRERES, 3>, a, st);
-        else if (mode == 1) launch_trio_k(mfma_trio_kernel<EPI_PRERES, 1>, a, st);
-        else launch_trio_k(mfma_trio_kernel<EPI_PRERES, 0>, a, st);
+        if (mode == 7 && a.rc_in == a.in && (a.allow & 8)) launch_trio_k<mfma_trio_kernel<EPI_PRERES, 15>>(a, st);      // the residual operand out of the input window
+        else if (mode == 7) launch_trio_k<mfma_trio_kernel<EPI_PRERES, 7>>(a, st);
+        else if (mode == 3) launch_trio_k<mfma_trio_kernel<EPI_PRERES, 3>>(a, st);
+        else if (mode == 1) launch_trio_k<mfma_trio_kernel<EPI_PRERES, 1>>(a, st);
+        else launch_trio_k<mfma_trio_kernel<EPI_PRERES, 0>>(a, st);
     } else if (epi_c == EPI_MID) {
-        if (mode == 7) launch_trio_k(mfma_trio_kernel<EPI_MID, 7>, a, st);
-        else if (mode == 3) launch_trio_k(mfma_trio_kernel<EPI_MID, 3>, a, st);
-        else if (mode == 1) launch_trio_k(mfma_trio_kernel<EPI_MID, 1>, a, st);
-        else launch_trio_k(mfma_trio_kernel<EPI_MID, 0>, a, st);
+        if (mode == 7) launch_trio_k<mfma_trio_kernel<EPI_MID, 7>>(a, st);
+        else if (mode == 3) launch_trio_k<mfma_trio_kernel<EPI_MID, 3>>(a, st);
+        else if (mode == 1) launch_trio_k<mfma_trio_kernel<EPI_MID, 1>>(a, st);
+        else launch_trio_k<mfma_trio_kernel<EPI_MID, 0>>(a, st);
     } else { set_error("trio: the third layer must be a hidden layer"); return 1; }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { set_error(std::string("trio launch failed: ") + hipGetErrorString(e)); return 1; }

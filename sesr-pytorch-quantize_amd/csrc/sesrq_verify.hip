@@ -1,3 +1,6 @@
+// Load-time proofs of sesrq_create: the input quantiser's fast division (below), the one-fma requant forms (prove_direct_requant,
+// prove_single_requant) and the static saturation bound of a layer (saturation_free).
+//
 // Verified fast division for the input quantiser.
 //
 // The reference quantises the frame with a TRUE fp32 division (myQL/quan_func.py:225):
@@ -83,7 +86,7 @@ FastDiv prove_fastdiv(float s, int zero) {
     if (ok && hipMalloc((void **)&d_bad, sizeof(*d_bad)) == hipSuccess && hipMemset(d_bad, 0, sizeof(*d_bad)) == hipSuccess) {
         auto run = [&](float a, float b) {   // all floats between a and b, same sign, |a| <= |b|
             const unsigned ua = __builtin_bit_cast(unsigned, a), ub = __builtin_bit_cast(unsigned, b);
-            hipLaunchKernelGGL(verify_fastdiv_kernel, dim3(4096), dim3(256), 0, 0, ua, ub, s, fd.r, z, d_bad);
+            launch_kernel<verify_fastdiv_kernel>(dim3(4096), dim3(256), 0, 0, ua, ub, s, fd.r, z, d_bad);
         };
         if (fd.xlo < 0.f) { run(-0.0f, fd.xlo); if (fd.xhi >= 0.f) run(0.0f, fd.xhi); else run(fd.xhi, fd.xlo); }   // (both negative: |xhi| <= |xlo|)
         else run(fd.xlo, fd.xhi);
@@ -152,5 +155,40 @@ bool prove_single_requant(unsigned M, unsigned n) {
     }
     return true;
 }
+
+
+// Load-time proof that the 18-bit PE clamp and the 20-bit adder clamp can never fire:
+// for q in [-128,127] (pad value included) the extreme PE sums are 127*S+ + 128*S- and
+// -(128*S+ + 127*S-).  (myQL/quan_func.py:358-370,437 are then identities.)
+// risky_oc (optional): bit o = some PE sum of output channel o can leave the accumulator range
+bool saturation_free(const sesrq_layer_desc &d, int zc, int acc_bits, int add_bits, long long &worst_pe,
+                            long long &worst_sum, int &risky_mask, int *risky_oc) {
+    risky_mask = 0;
+    if (risky_oc) *risky_oc = 0;
+    const int taps = d.k * d.k;
+    const long long acc_hi = (1LL << (acc_bits - 1)) - 1, add_hi = (1LL << (add_bits - 1)) - 1;
+    worst_pe = worst_sum = 0;
+    bool ok = (zc >= -128 && zc <= 127);
+    if (!ok) { risky_mask = 15; if (risky_oc) *risky_oc = 0xffff; }
+    for (int o = 0; o < d.oc; ++o) {
+        long long tot_hi = 0, tot_lo = 0;
+        for (int p = 0; p < 4; ++p) {
+            long long sp = 0, sn = 0;
+            for (int c = p; c < d.ic; c += 4)
+                for (int t = 0; t < taps; ++t) {
+                    const int w = d.w[((size_t)o * d.ic + c) * taps + t];
+                    if (w > 0) sp += w; else sn -= w;
+                }
+            const long long hi = 127 * sp + 128 * sn, lo = 128 * sp + 127 * sn;
+            worst_pe = std::max(worst_pe, std::max(hi, lo));
+            if (hi > acc_hi || lo > acc_hi + 1) { ok = false; risky_mask |= 1 << p; if (risky_oc) *risky_oc |= 1 << o; }
+            tot_hi += hi; tot_lo += lo;
+        }
+        worst_sum = std::max(worst_sum, std::max(tot_hi, tot_lo));
+        if (tot_hi > add_hi || tot_lo > add_hi + 1) ok = false;
+    }
+    return ok;
+}
+
 
 }  // namespace sesrq

@@ -16,7 +16,7 @@ MAX_LAYERS = 16
 MAX_CH = 16
 F32, I8 = 0, 1
 ENGINE_AUTO, ENGINE_DOT4, ENGINE_MFMA = 0, 1, 2
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 
 class LayerDesc(C.Structure):
@@ -35,7 +35,7 @@ class NetDesc(C.Structure):
 class Options(C.Structure):
     _fields_ = [("engine", C.c_int32), ("force_general", C.c_int32), ("exact_div", C.c_int32),
                 ("anchor_add", C.c_int32), ("fuse_hidden", C.c_int32), ("wg_budget", C.c_int32),
-                ("i8_in_scale", C.c_float), ("i8_in_zero", C.c_int32)]
+                ("i8_in_scale", C.c_float), ("i8_in_zero", C.c_int32), ("reduced_forms", C.c_int32)]
 
 
 class CalibConvDesc(C.Structure):
@@ -50,7 +50,7 @@ class FrameIO(C.Structure):
 
 class Taps(C.Structure):
     _fields_ = [("act", C.c_void_p * MAX_LAYERS), ("pe_out", C.c_void_p * MAX_LAYERS),
-                ("pe_add", C.c_void_p * MAX_LAYERS), ("overflow", C.c_void_p)]
+                ("pe_add", C.c_void_p * MAX_LAYERS), ("overflow", C.c_void_p), ("shortcut", C.c_void_p), ("ic", C.c_void_p)]
 
 
 # every symbol include/sesrq.h declares: name -> (restype, argtypes)
@@ -66,7 +66,11 @@ SYMBOLS = {
     "sesrq_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                 C.c_void_p, C.c_size_t, C.c_void_p]),
     "sesrq_forward_many": (C.c_int, [C.c_void_p, C.POINTER(FrameIO), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
-                                     C.POINTER(C.c_void_p), C.c_size_t, C.POINTER(C.c_void_p), C.c_int]),
+                                     C.POINTER(C.c_void_p), C.c_size_t, C.POINTER(C.c_void_p), C.c_int, C.c_int]),
+    "sesrq_submit_selftest": (C.c_int, [C.c_int, C.c_int]),
+    "sesrq_instance_count": (C.c_int, []),
+    "sesrq_instance_name": (C.c_char_p, [C.c_int]),
+    "sesrq_instance_launches": (C.c_longlong, [C.c_int]),
     "sesrq_forward_debug": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
                                       C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.POINTER(Taps)]),
     "sesrq_forward_timed": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
@@ -113,6 +117,12 @@ def lib() -> C.CDLL:
             fn.restype, fn.argtypes = res, args
         _lib = handle
     return _lib
+
+
+def instances():
+    """{name: launches so far} of every kernel instantiation the library can select (sesrq_instance_*)."""
+    l = lib()
+    return {l.sesrq_instance_name(i).decode(): int(l.sesrq_instance_launches(i)) for i in range(l.sesrq_instance_count())}
 
 
 def last_error() -> str:

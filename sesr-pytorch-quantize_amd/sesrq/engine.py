@@ -102,7 +102,7 @@ class Submission:
             c = min(count, N)
             off = k % N
             _lib.check(lib.sesrq_forward_many(self.engine._h, C.cast(base + off * sz, C.POINTER(_lib.FrameIO)), c, self.dt, n, H, W,
-                                              self.ws_rot[off % self.S], self.ws_bytes, self.st_rot[off % self.S], self.S))
+                                              self.ws_rot[off % self.S], self.ws_bytes, self.st_rot[off % self.S], self.S, self.group))
             k += c
             count -= c
 
@@ -113,11 +113,14 @@ class Engine:
 
     def __init__(self, bundle: Bundle, device: Optional[torch.device] = None, engine: int = _lib.ENGINE_AUTO,
                  force_general: bool = False, exact_division: bool = False, anchor_add: bool = False,
-                 fuse_hidden=1, wg_budget: int = 0, upstream: Optional[Bundle] = None, reciprocal_division: bool = False):
+                 fuse_hidden=1, wg_budget: int = 0, upstream: Optional[Bundle] = None, reciprocal_division: bool = False,
+                 reduced_forms: int = -1):
         """reciprocal_division: form x / s0 of the input quantiser as x * fl(1/s0) -- torch's tensor / scalar on a GPU --
         instead of the true quotient the CPU-run reference and the goldens define (sesrq_options.exact_div = 2).
         upstream: the net whose int8 OUTPUT frames this engine takes as int8 input (chained nets, e.g. nrdm_6 ->
-        SESR-x2): they are re-quantised into this net's input domain while the first layer stages them."""
+        SESR-x2): they are re-quantised into this net's input domain while the first layer stages them.
+        reduced_forms: sesrq_options.reduced_forms -- which of the proven reduced epilogue forms the kernels may select (-1 = all); same
+        bits either way, it only picks the kernel instantiation (tests run every one of them on reference-made data)."""
         if not torch.cuda.is_available():
             raise RuntimeError("sesrq.Engine needs a HIP device (torch.cuda.is_available() is False); "
                                "there is no CPU fallback in this package")
@@ -150,6 +153,7 @@ class Engine:
         opts.anchor_add = int(bool(anchor_add))
         opts.fuse_hidden = 1 if fuse_hidden is True else int(fuse_hidden)     # 0 per layer, 1 (default) fused hidden trios
         opts.wg_budget = int(wg_budget)
+        opts.reduced_forms = int(reduced_forms)
         if upstream is not None:
             opts.i8_in_scale = float(np.float32(upstream.scale[upstream.L]))
             opts.i8_in_zero = int(upstream.zero[upstream.L])
@@ -303,14 +307,17 @@ class Engine:
                                                       ws.data_ptr(), ws.numel(), st, iters, launch_ms, C.byref(fwd)))
         return list(launch_ms), float(fwd.value)
 
-    def forward_debug(self, x: torch.Tensor, pe: bool = True, overflow: bool = False, acts: bool = True):
+    def forward_debug(self, x: torch.Tensor, pe: bool = True, overflow: bool = False, acts: bool = True, special: bool = False):
         """Forward with the reference's dump taps (define.py *_W_FLG): returns a dict with
         q_out, y, input{k} (int8 NCHW), pe_out{k} (N,4,OC,H,W int32), pe_add{k} (N,OC,H,W int32) and, with
         overflow=True, `overflow` (L,2) int32: PE sums above / below the accumulator range before saturation --
         the events the reference prints as max_overflow / min_overflow (quan_func.py:358-361).
         On the MFMA engine the PE taps are written by the per-PE MFMA kernels themselves; the quantised-input tap
         (input0), the overflow counters and the pe-split last layer (OC <= 4) run their layer on the dot4 kernels.
-        acts=False: no input{k} taps (layer 0 then stays on its MFMA kernel too)."""
+        acts=False: no input{k} taps (layer 0 then stays on its MFMA kernel too).
+        special=True: also `shortcut` (N, OC_0, H, W) fp32 = the reference's residual/shortcut_tensor.pt (layer 0's un-rounded ReLU'd requant
+        output, quan_func.py:529-549) and `input4_special` (N, OC_{L-2}, H, W) int8 = input.4.spcial.pt (ic, quan_func.py:250-254); both are
+        taps of the dot4 kernels (layers 0 and L-2 then run there)."""
         dt = self._check_in(x)
         with torch.cuda.device(self.device):
             x = x.contiguous()
@@ -330,6 +337,12 @@ class Engine:
                     res[f"pe_add{k}"] = torch.empty((N, oc, H, W), dtype=torch.int32, device=self.device)
                     taps.pe_out[k] = res[f"pe_out{k}"].data_ptr()
                     taps.pe_add[k] = res[f"pe_add{k}"].data_ptr()
+            if special:
+                l0, lm = self.bundle.layers[0], self.bundle.layers[L - 2]
+                res["shortcut"] = torch.empty((N, l0.wq.shape[0], H, W), dtype=torch.float32, device=self.device)
+                res["input4_special"] = torch.empty((N, lm.wq.shape[0], H, W), dtype=torch.int8, device=self.device)
+                taps.shortcut = res["shortcut"].data_ptr()
+                taps.ic = res["input4_special"].data_ptr()
             if overflow:
                 res["overflow"] = torch.zeros((L, 2), dtype=torch.int32, device=self.device)
                 taps.overflow = res["overflow"].data_ptr()

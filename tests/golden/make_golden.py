@@ -45,6 +45,13 @@ CASES = {
     # x2sesr.pth.tar is refused by torch.load(weights_only=True) (pickled optimizer object),
     # so the x2 topology is driven with the reference's own random initialisation, seeded.
     "sesr_x2_rand": dict(mflag=6, ckpt=None, inp="rand_DM_Input_80x960.pt", qat=False, seed=1234),
+    # Round 5: the same nets on a NATURAL-ISH frame (tests/golden/natural.py: gradients + edges + flat areas + 2 % noise, min > 0) and
+    # CALIBRATED ON THAT FRAME by the reference's own mode-0 pass (test.py:185-217 semantics): zero_0 < -128 together with its consistent
+    # scale, bias constants that are not saturated -- what a real image gives and no noise fixture has.  big: a BASELINE-size frame of
+    # the same kind run through the reference's sim path with the same calibration (dump flags off), pinned by SHA-256.
+    "sesr_x4_nat":      dict(mflag=5, ckpt="model_params/x4sesr.pth", inp="natural", qat=False, nat_seed=2024, big=(540, 960)),
+    "nrdm_3_nat":       dict(mflag=3, ckpt="model_params/nrdm_3_raw_G.pth", inp="natural", qat=False, nat_seed=2025, big=(540, 960)),
+    "sesr_x2_rand_nat": dict(mflag=6, ckpt=None, inp="natural", qat=False, seed=1234, nat_seed=2026, big=(1080, 1920)),
 }
 CROP_H, CROP_W = 24, 40
 
@@ -119,7 +126,13 @@ def run_case(name: str, out_dir: str, time_1080p: bool = False) -> None:
                                     "bias_width": define.BIAS_BIT, "pe_num": define.PE, "exe_mode": qmode}))
         return model
 
-    x_full = torch.load(os.path.join(REF, cfg["inp"]), weights_only=True, map_location="cpu").float()
+    natural = cfg["inp"] == "natural"
+    if natural:
+        sys.path.insert(0, HERE)
+        from natural import natural_frame, interesting_crop
+        x_full = torch.from_numpy(natural_frame(1 if cfg["mflag"] == 5 else 3, 80, 960, cfg["nat_seed"]))
+    else:
+        x_full = torch.load(os.path.join(REF, cfg["inp"]), weights_only=True, map_location="cpu").float()
     if x_full.shape[1] != (1 if cfg["mflag"] == 5 else 3):
         raise SystemExit("unexpected input shape")
 
@@ -167,6 +180,8 @@ def run_case(name: str, out_dir: str, time_1080p: bool = False) -> None:
                     M_res=int(ld("output_pt/requan_factor/requan_res.pt")),
                     n_res=int(ld("output_pt/requan_factor/n_res.pt")),
                     H=int(x.shape[2]), W=int(x.shape[3]), out_shape=list(y.shape), sha={})
+        if natural:
+            meta.update(input="natural", nat_seed=cfg["nat_seed"], x_sha256=sha(x.numpy().astype(np.float32)))
         acts = {f"input{k}": ld(f"output_pt/input/input.{k}.pt").numpy() for k in range(6)}
         acts["input4_special"] = ld("output_pt/input/input.4.spcial.pt").numpy()
         for k, v in acts.items():
@@ -242,7 +257,6 @@ def run_case(name: str, out_dir: str, time_1080p: bool = False) -> None:
             y = sim_run(x)
             secs.append(time.perf_counter() - t0)
         # graph construction (quantize_model_weight + four fx rewrites) is inside sim_run like it is inside sim.py's run; the forward alone:
-        m_secs = []
         # dump flags are off, so input.5 is not on disk: the int8 frame is recovered from the float result, y = (q5 - z5) * f32(s5) after PixelShuffle
         s5 = np.float32(torch.load("output_pt/input/input.5.scale.pt")); z5 = int(torch.load("output_pt/input/input.5.zero.pt"))
         yq = np.rint(y.numpy().astype(np.float64) / np.float64(s5) + z5)
@@ -265,6 +279,37 @@ def run_case(name: str, out_dir: str, time_1080p: bool = False) -> None:
     # (1) full frame
     y = sim_run(x_full)
     harvest(x_full, y, "full", full=True)
+    if natural:
+        # the crop with every stage stored: where the frame has an edge, a flat area and gradient inside 24 x 40
+        cy, cx = interesting_crop(x_full.numpy(), CROP_H, CROP_W)
+        x_crop = x_full[:, :, cy:cy + CROP_H, cx:cx + CROP_W].contiguous()
+        y = sim_run(x_crop)
+        harvest(x_crop, y, "crop", full=False)
+        # a BASELINE-size frame of the same kind through the reference's sim path, same calibration, the seven dump switches off
+        # (bound by value inside quan_func at import: set on the module); the int8 frame is recovered from the float result
+        import time
+        for flg in ("WEIGHT_W_FLG", "INPUT_W_FLG", "BIAS_W_FLG", "BIAS_QUAN_W_FLG", "OUTPUT_PE_W_FLG", "OUTPUT_PE_ADD_W_FLG", "REQUAN_FACTOR_W_FLG"):
+            assert hasattr(qf, flg), flg
+            setattr(qf, flg, False)
+        Hb, Wb = cfg["big"]
+        xb = torch.from_numpy(natural_frame(x_full.shape[1], Hb, Wb, cfg["nat_seed"] + 100))
+        t0 = time.perf_counter()
+        yb = sim_run(xb)
+        secs = time.perf_counter() - t0
+        s5 = np.float32(torch.load("output_pt/input/input.5.scale.pt")); z5 = int(torch.load("output_pt/input/input.5.zero.pt"))
+        yq = np.rint(yb.numpy().astype(np.float64) / np.float64(s5) + z5)
+        assert yq.min() >= -128 and yq.max() <= 127
+        yq = yq.astype(np.int8)
+        assert np.array_equal(((yq.astype(np.float32) - np.float32(z5)) * s5).astype(np.float32), yb.numpy().astype(np.float32))
+        rec = dict(case=name, bundle=f"{name}.crop.npz", input=f"natural_frame({x_full.shape[1]}, {Hb}, {Wb}, seed={cfg['nat_seed'] + 100}) (tests/golden/natural.py)",
+                   nat_seed=cfg["nat_seed"] + 100, in_shape=list(xb.shape), out_shape=list(yb.shape), seconds=round(secs, 3),
+                   x_sha256=sha(xb.numpy()), out_q_sha256=sha(yq), out_f_sha256=sha(yb.numpy().astype(np.float32)),
+                   cores=torch.get_num_threads(), torch=torch.__version__)
+        json.dump(rec, open(os.path.join(out_dir, f"{name}.big.json"), "w"), indent=1)
+        print(json.dumps(rec, indent=1), flush=True)
+        os.chdir(HERE)
+        shutil.rmtree(scratch, ignore_errors=True)
+        return
     # (2) crop, all stages kept
     x_crop = x_full[:, :, 8:8 + CROP_H, 100:100 + CROP_W].contiguous()
     y = sim_run(x_crop)

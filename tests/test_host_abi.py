@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(handle, n), f"libsesrq.so lacks {n}"
     assert sorted(_lib.SYMBOLS) == names, "python binding and header disagree"
-    assert _lib.lib().sesrq_version() == _lib.ABI_VERSION == 3
+    assert _lib.lib().sesrq_version() == _lib.ABI_VERSION == 4
 
 
 def test_requant_const_matches_reference_table():

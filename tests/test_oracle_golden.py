@@ -7,7 +7,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import golden_files, load_fixture, fixture_input, GOLDEN
+from conftest import golden_files, load_fixture, fixture_input, big_cases, big_input, GOLDEN
 from oracle import sesrq_oracle as O
 
 STAGE_FILES = [f for f in golden_files() if not f.endswith((".params.npz", "tables.npz", ".stimtxt.npz", ".anchor.npz"))]
@@ -53,6 +53,23 @@ def test_c_oracle_matches_the_reference_at_config2_size():
     r = CO.forward(net, x, threads=min(os.cpu_count() or 1, 8), want_f=True)
     assert list(r["q_out"].shape) == ref["out_shape"]
     assert _sha(r["q_out"]) == ref["out_q_sha256"] and _sha(r["y"]) == ref["out_f_sha256"]
+
+
+BIG = big_cases()
+
+
+@pytest.mark.parametrize("rec", [r for _, r in BIG], ids=[r["case"] for _, r in BIG])
+def test_c_oracle_matches_the_reference_on_baseline_size_natural_frames(rec):
+    """Round 5: natural-ish frames at BASELINE sizes (SESR-x2 1080p = config 2, nrdm_3 540p = config 3, SESR-x4 540p = config 4's frame)
+    through the reference's own sim path, calibrated by the reference on a natural frame (zero_0 < -128 from calibration; the x2 net's
+    18-bit PE clamp fires on it: the reference printed max_overflow).  The C oracle reproduces the SHA-256 of the int8 and fp32 results."""
+    from oracle import c_oracle as CO
+    fx, meta = load_fixture(os.path.join(GOLDEN, rec["bundle"]))
+    assert meta["zero"][0] < -128
+    net = O.net_from_fixture(fx)
+    r = CO.forward(net, big_input(rec), threads=min(os.cpu_count() or 1, 8), want_f=True)
+    assert list(r["q_out"].shape) == rec["out_shape"]
+    assert _sha(r["q_out"]) == rec["out_q_sha256"] and _sha(r["y"]) == rec["out_f_sha256"]
 
 
 def test_qconst_table():
