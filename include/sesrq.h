@@ -137,6 +137,10 @@ int sesrq_layer_one_fma(const sesrq_net *net, int k);
  * not, but the single-rounding form is, 0 = neither.  No reference counterpart. */
 int sesrq_requant_form(uint32_t M, uint32_t n, int output_layer);
 
+/* Channel geometry of a created net: input channels, output channels of the last conv (before PixelShuffle), PixelShuffle factor -- what a
+ * caller needs to size the output of sesrq_forward, (N, cout / r^2, H * r, W * r) (csrc/torch_op/sesrq_torch_op.cpp does). */
+int sesrq_net_shape(const sesrq_net *net, int *cin, int *cout, int *pixel_shuffle);
+
 /* Bytes of device workspace sesrq_forward needs for N frames of H x W (caller-owned). */
 size_t sesrq_workspace_bytes(const sesrq_net *net, int N, int H, int W);
 

@@ -1021,10 +1021,12 @@ static void launch(ConvArgs a, hipStream_t st, int tile_h = MTH) {
     launch_kernel<KERN>(grid, dim3(256), 0, st, a);
 }
 
-// hybrid first layer on the sparse MFMA, by the register that needs the clamp (3 input channels only: a.afrag_sp is set for nothing else)
+// hybrid first layer.  3 input channels: always the sparse MFMA (sesrq_create packs the 2:4 images for every 3-channel layer with exactly
+// one risky PE -- PE 3 holds no channel), by the register that needs the clamp; other channel counts: the dense hybrid kernel.
 template <int SRC, bool RC, int NCH>
-static void launch_f5_sparse(const ConvArgs &a, hipStream_t st) {
+static int launch_f5_hybrid(const ConvArgs &a, hipStream_t st) {
     if constexpr (NCH == 3) {
+        if (!a.afrag_sp) { set_error("mfma: hybrid 3-channel first layer without its sparse weight image"); return 1; }
         switch (a.risky_reg) {
             case 0: launch<mfma_f5_kernel_w4<HYBS, SRC, RC, 3, 0>>(a, st, F5_TH); break;
             case 1: launch<mfma_f5_kernel_w4<HYBS, SRC, RC, 3, 1>>(a, st, F5_TH); break;
@@ -1035,6 +1037,7 @@ static void launch_f5_sparse(const ConvArgs &a, hipStream_t st) {
     } else {
         launch<mfma_f5_kernel_w4<HYB, SRC, RC, NCH>>(a, st, F5_TH);
     }
+    return 0;
 }
 
 #define SESRQ_BY_MODE(KERN, ...)                                                         \
@@ -1117,8 +1120,7 @@ int launch_mfma(const LayerPlan &lp, const ConvArgs &a_in, int src, int epi, boo
 #define SESRQ_F5(...)                                                                    \
     do {                                                                                 \
         if (mode == MERGED) launch<mfma_f5_kernel_w4<MERGED, __VA_ARGS__>>(a, st, F5_TH);       \
-        else if (mode == HYB && a.afrag_sp) launch_f5_sparse<__VA_ARGS__>(a, st);        \
-        else if (mode == HYB) launch<mfma_f5_kernel_w4<HYB, __VA_ARGS__>>(a, st, F5_TH);        \
+        else if (mode == HYB) { if (launch_f5_hybrid<__VA_ARGS__>(a, st)) return 1; }    \
         else if (mode == GEN_STD) launch<mfma_f5_kernel<GEN_STD, __VA_ARGS__>>(a, st, F5_TH);   \
         else launch<mfma_f5_kernel<GEN_ANY, __VA_ARGS__>>(a, st, F5_TH);                        \
     } while (0)

@@ -53,7 +53,16 @@ const char *sesrq_layer_engine(const sesrq_net *net, int k) {
 
 int sesrq_layer_one_fma(const sesrq_net *net, int k) {
     if (!net || k < 0 || k >= net->L) return 0;
-    return net->layers[k].base.direct;      // 1 = one fma, 2 = one fma + the add of 128 (output layer only)
+    // 1 = one fma, 2 = one fma + the add of 128 (output layer only).  First and output layer: sesrq_create has applied
+    // sesrq_options.reduced_forms already; a hidden layer's proof is used by the fused trio only, under bit 2 (layers a, b) / bit 4 (third layer)
+    int d = net->layers[k].base.direct;
+    if (k > 0 && k < net->L - 1) {
+        int bit = 2;
+        for (int j = std::max(1, k - 2); j <= k; ++j)
+            if (net->trio_len[j] == 3 && k == j + 2) bit = 4;
+        if (!(net->reduced_forms & bit)) d = 0;
+    }
+    return d;
 }
 
 int sesrq_launch_plan(const sesrq_net *net, int *first, int *count) {
@@ -67,6 +76,14 @@ int sesrq_launch_plan(const sesrq_net *net, int *first, int *count) {
         k += c;
     }
     return n;
+}
+
+int sesrq_net_shape(const sesrq_net *net, int *cin, int *cout, int *pixel_shuffle) {
+    if (!net) { set_error("sesrq_net_shape: null net"); return 1; }
+    if (cin) *cin = net->layers[0].ic;
+    if (cout) *cout = net->layers[net->L - 1].oc;
+    if (pixel_shuffle) *pixel_shuffle = net->ps;
+    return 0;
 }
 
 size_t sesrq_workspace_bytes(const sesrq_net *net, int N, int H, int W) {
@@ -171,8 +188,8 @@ int forward_impl(const sesrq_net *net, const void *in, int in_dtype, void *out_q
             a.dbg_pe = (int *)taps->pe_out[k];
             a.dbg_add = (int *)taps->pe_add[k];
             a.dbg_ovf = taps->overflow ? (int *)taps->overflow + 2 * k : nullptr;
-            if (k == 0) { a.dbg_q0 = (signed char *)taps->act[0]; a.dbg_t = (float *)taps->shortcut; }
             if (k == L - 2) a.dbg_ic = (signed char *)taps->ic;
+            if (k == 0) { a.dbg_q0 = (signed char *)taps->act[0]; a.dbg_t = (float *)taps->shortcut; }
             else if (taps->act[k] && launch_unpack_nhwc16(cur, (signed char *)taps->act[k], N, lp.ic, H, W, st)) {
                 set_error("sesrq_forward: debug unpack launch failed"); return 1;
             }

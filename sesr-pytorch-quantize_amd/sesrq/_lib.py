@@ -62,6 +62,7 @@ SYMBOLS = {
     "sesrq_fast_division_proven": (C.c_int, [C.c_void_p]),
     "sesrq_layer_one_fma": (C.c_int, [C.c_void_p, C.c_int]),
     "sesrq_requant_form": (C.c_int, [C.c_uint32, C.c_uint32, C.c_int]),
+    "sesrq_net_shape": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "sesrq_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_int, C.c_int, C.c_int]),
     "sesrq_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                 C.c_void_p, C.c_size_t, C.c_void_p]),

@@ -63,8 +63,11 @@ class Submission:
     """Frames, buffers and streams of Engine.submission(), laid out once as the C arrays sesrq_forward_many takes."""
 
     def __init__(self, engine, frames, outs_q, outs_f, streams, group=1):
-        if not frames or not streams or len(frames) != len(outs_q) or (outs_f is not None and len(outs_f) != len(frames)):
+        if not frames or not streams or (outs_q is None and outs_f is None):
             raise ValueError("submission: frames / outputs / streams do not match")
+        for o in (outs_q, outs_f):
+            if o is not None and len(o) != len(frames):
+                raise ValueError("submission: frames / outputs / streams do not match")
         if len(frames) % len(streams):
             raise ValueError("submission: the frame list must be a multiple of the stream count (frame k runs on stream k % S, cyclically)")
         self.engine, self.n = engine, len(frames)
@@ -75,18 +78,33 @@ class Submission:
         for k, x in enumerate(frames):
             if engine._check_in(x) != self.dt or tuple(x.shape) != tuple(frames[0].shape) or not x.is_contiguous():
                 raise ValueError("submission: every frame must be a contiguous tensor of the same shape and dtype")
-            if tuple(outs_q[k].shape) != tuple(shp) or outs_q[k].dtype != torch.int8 or not outs_q[k].is_contiguous():
-                raise ValueError("submission: every int8 output must be a contiguous tensor of the forward's output shape")
-        self._keep = (list(frames), list(outs_q), list(outs_f) if outs_f is not None else None, list(streams))
+            for o, dtp, what in ((outs_q, torch.int8, "int8"), (outs_f, torch.float32, "fp32")):
+                if o is not None and (tuple(o[k].shape) != tuple(shp) or o[k].dtype != dtp or not o[k].is_contiguous()):
+                    raise ValueError(f"submission: every {what} output must be a contiguous tensor of the forward's output shape")
+        self._keep = (list(frames), list(outs_q) if outs_q is not None else None, list(outs_f) if outs_f is not None else None, list(streams))
         # two periods back to back: any window of up to n frames starting anywhere in the cycle is one contiguous slice
         self.io = (_lib.FrameIO * (2 * self.n))()
         for k in range(2 * self.n):
             j = k % self.n
-            self.io[k] = _lib.FrameIO(frames[j].data_ptr(), outs_q[j].data_ptr(), outs_f[j].data_ptr() if outs_f is not None else None)
+            self.io[k] = _lib.FrameIO(frames[j].data_ptr(), outs_q[j].data_ptr() if outs_q is not None else None,
+                                      outs_f[j].data_ptr() if outs_f is not None else None)
         S = len(streams)
         if group < 1 or (group > 1 and N != 1):
             raise ValueError("submission: group >= 1, and grouping needs single-image frames")
         self.group = int(group)
+        if self.group > 1:      # the frames of one launch sequence are written concurrently (the library refuses a shared buffer too)
+            for o in (outs_q, outs_f):
+                if o is None:
+                    continue
+                for s_ in range(S):
+                    seq = [t.data_ptr() for t in o[s_::S]]
+                    g_eff = min(self.group, len(seq))      # one call hands over at most one period: a group never wraps onto its own frames
+                    ring = seq + seq[:g_eff - 1]
+                    for i in range(len(seq)):
+                        win = ring[i:i + g_eff]
+                        if len(set(win)) != len(win):
+                            raise ValueError("submission: frames that may share a launch sequence (any `group` consecutive frames of a "
+                                             "stream) share an output buffer")
         self.ws = [engine.workspace(N * self.group, H, W, s) for s in range(S)]       # room for `group` frames per launch sequence
         self.ws_bytes = self.ws[0].numel()
         # the library maps frame k of a call to streams[k % S]: a window that starts at frame f of the list gets the arrays rotated by f % S
@@ -164,6 +182,9 @@ class Engine:
         self._ws: Dict[tuple, torch.Tensor] = {}
 
     def close(self):
+        if getattr(self, "_op_id", None):      # registered as a torch.ops.sesrq.forward handle: the C++ side drops its pointer first
+            from . import torch_op
+            torch_op.unregister_engine(self)
         if getattr(self, "_h", None):
             _lib.lib().sesrq_destroy(self._h)
             self._h = None
@@ -274,7 +295,7 @@ class Engine:
     __call__ = forward
 
     def submission(self, frames, outs_q, streams, outs_f=None, group: int = 1):
-        """A prepared batch of independent forwards for sesrq_forward_many: frame k = frames[k] -> outs_q[k] (/ outs_f[k]) on
+        """A prepared batch of independent forwards for sesrq_forward_many: frame k = frames[k] -> outs_q[k] (/ outs_f[k]; either may be None) on
         streams[k % len(streams)] with workspace slot k % len(streams).  Returns a Submission; .enqueue(count, first=0) issues frames
         first .. first+count-1 of the (cyclically repeated) list with ONE call into the library -- for callers whose frames are so small
         that the host's per-call cost bounds the rate.  group = G > 1 (single-image frames only): the per-stream workspaces are sized

@@ -226,7 +226,7 @@ class SesrqGraphModule(torch.fx.GraphModule):
                                  "(quan_func.py:373); got a batch of %d frames" % x.shape[0])
             # (with a dump flag on, every forward runs a second, debug forward on the per-PE kernels: sesrq_forward_debug)
             res = eng.forward_debug(x.float() if x.dtype != torch.int8 else x,
-                                    pe=flags["OUTPUT_PE_W_FLG"] or flags["OUTPUT_PE_ADD_W_FLG"])
+                                    pe=flags["OUTPUT_PE_W_FLG"] or flags["OUTPUT_PE_ADD_W_FLG"], special=flags["INPUT_W_FLG"])
             r = b.pixel_shuffle
             for k in range(L):
                 if flags["INPUT_W_FLG"]:
@@ -236,6 +236,11 @@ class SesrqGraphModule(torch.fx.GraphModule):
                         STORE[f"pe_out/pe_output{k}_{p}"] = res[f"pe_out{k}"][0, p].float().cpu()
                 if flags["OUTPUT_PE_ADD_W_FLG"]:
                     STORE[f"pe_add/pe_add_output{k}"] = res[f"pe_add{k}"].float().cpu()
+            if flags["INPUT_W_FLG"]:
+                # the two tensors the reference writes unconditionally beside the activations (round 5): layer 0's un-rounded ReLU'd requant
+                # output (quan_func.py:549) and the merging layer's re-quantised operand ic (quan_func.py:254, "spcial" is the reference's spelling)
+                STORE["residual/shortcut_tensor"] = res["shortcut"].cpu()
+                STORE[f"input/input.{L - 1}.spcial"] = res["input4_special"].float().cpu()
             if flags["INPUT_W_FLG"]:        # input.L.pt: the int8 result before PixelShuffle (quan_func.py:592)
                 qL = res["q_out"].float()
                 STORE[f"input/input.{L}"] = (torch.nn.functional.pixel_unshuffle(qL, r) if r > 1 else qL).cpu()

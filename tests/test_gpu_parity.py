@@ -57,7 +57,7 @@ def test_golden_stage_by_stage(path, eng):
     xt = torch.from_numpy(x).to(_dev())
     # the PE dump taps: dot4 kernels on the dot4 engine, the per-PE MFMA kernels themselves (GEN_TAP) on the MFMA engine
     use_pe = eng[0] in ("dot4", "mfma")
-    res = e.forward_debug(xt, pe=use_pe)
+    res = e.forward_debug(xt, pe=use_pe, special=True)       # special: shortcut_tensor.pt / input.4.spcial.pt (quan_func.py:549, :254)
     if eng[0] != "dot4":
         assert all(s.startswith("mfma") for s in e.layer_engines()), e.layer_engines()
         names = e.layer_engines()
@@ -74,12 +74,13 @@ def test_golden_stage_by_stage(path, eng):
     q5 = got["q_out"].reshape(N, C, Ho // r, r, Wo // r, r).transpose(0, 1, 3, 5, 2, 4).reshape(N, C * r * r, Ho // r, Wo // r)
     got["input5"] = q5
     got["out"] = got["y"]
+    assert got["shortcut"].dtype == np.float32 and got["input4_special"].dtype == np.int8
     for k in range(5):
         if use_pe:
             got[f"pe_out{k}"] = got[f"pe_out{k}"][0]
     for name, want_sha in meta["sha"].items():
-        if name in ("shortcut", "input4_special") or (name.startswith("pe_") and not use_pe):
-            continue     # fp32 shortcut / its re-quantisation are internal to the fused epilogues
+        if name.startswith("pe_") and not use_pe:
+            continue
         assert _sha(got[name]) == want_sha, f"{name} differs from the reference"
     for name in fx.files:
         if name in got and name not in ("x",):
@@ -88,10 +89,16 @@ def test_golden_stage_by_stage(path, eng):
         res2 = e.forward_debug(xt, pe=True, acts=False)
         for nm in ("pe_out0", "pe_add0", "pe_out4", "pe_add4", "q_out"):
             assert torch.equal(res2[nm], res[nm]), nm
-    # production call (no taps; this is where the fused hidden trio runs) must give the same result
+    # production call (no taps; this is where the fused hidden trio runs) must give the same result -- in each of its three output kinds:
+    # they are different kernel instantiations of the last layer (round 4's wrong bytes lived in the int8-only one)
+    for wq, wf in ((True, False), (False, True), (True, True)):
+        q, y = e.forward(xt, want_q=wq, want_f=wf)
+        assert (q is None) == (not wq) and (y is None) == (not wf)
+        if wq:
+            _cmp(f"q_out(production, q={wq}, f={wf})", q, got["q_out"])
+        if wf:
+            _cmp(f"y(production, q={wq}, f={wf})", y, got["y"])
     q, y = e.forward(xt)
-    _cmp("q_out(production)", q, got["q_out"])
-    _cmp("y(production)", y, got["y"])
     _cmp("q_out(production) vs golden input5", np.ascontiguousarray(q.cpu().numpy().reshape(N, C, Ho // r, r, Wo // r, r).transpose(0, 1, 3, 5, 2, 4).reshape(q5.shape)), fx["input5"])
 
 
@@ -855,9 +862,36 @@ def test_forward_many_gives_sesrq_forward_bytes():
     io = (_lib.FrameIO * 2)(_lib.FrameIO(xs[0].data_ptr(), outs[0].data_ptr(), None), _lib.FrameIO(xs[1].data_ptr(), None, None))
     ws = e.workspace(1, 45, 130, 0)
     rc = _lib.lib().sesrq_forward_many(e._h, io, 2, _lib.F32, 1, 45, 130, (C.c_void_p * 1)(ws.data_ptr()), ws.numel(),
-                                       (C.c_void_p * 1)(torch.cuda.current_stream().cuda_stream), 1)
+                                       (C.c_void_p * 1)(torch.cuda.current_stream().cuda_stream), 1, 1)
     assert rc != 0 and "frame 1" in _lib.last_error()
     torch.cuda.synchronize()
+    # round 5 (ABI v4): the group size is an ARGUMENT, validated -- a workspace that happens to hold more frames changes nothing
+    big = e.workspace(8, 45, 130, 7)
+    st1 = (C.c_void_p * 1)(torch.cuda.current_stream().cuda_stream)
+    io2 = (_lib.FrameIO * 4)(*[_lib.FrameIO(xs[k].data_ptr(), outs[0].data_ptr(), None) for k in range(4)])      # ONE output buffer, stream-ordered
+    for o in outs:
+        o.zero_()
+    assert _lib.lib().sesrq_forward_many(e._h, io2, 4, _lib.F32, 1, 45, 130, (C.c_void_p * 1)(big.data_ptr()), big.numel(), st1, 1, 1) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(outs[0], want[3][0])          # group 1: legal, the last frame of the stream wins
+    # ... and grouped frames that share an output buffer are REFUSED (they would be written concurrently), nothing of the group enqueued
+    outs[0].zero_()
+    torch.cuda.synchronize()
+    rc = _lib.lib().sesrq_forward_many(e._h, io2, 4, _lib.F32, 1, 45, 130, (C.c_void_p * 1)(big.data_ptr()), big.numel(), st1, 1, 4)
+    assert rc != 0 and "share a launch sequence" in _lib.last_error(), _lib.last_error()
+    torch.cuda.synchronize()
+    assert int(outs[0].abs().sum()) == 0
+    with pytest.raises(ValueError, match="share an output buffer"):
+        e.submission(xs[:4], [outs[0]] * 4, streams[:1], group=4)
+    for bad_group, msg in ((0, "group must be"), (9, "group must be")):
+        assert _lib.lib().sesrq_forward_many(e._h, io2, 4, _lib.F32, 1, 45, 130, (C.c_void_p * 1)(big.data_ptr()), big.numel(), st1, 1, bad_group) != 0
+        assert msg in _lib.last_error()
+    small = e.workspace(1, 45, 130, 8)
+    assert _lib.lib().sesrq_forward_many(e._h, io2, 4, _lib.F32, 1, 45, 130, (C.c_void_p * 1)(small.data_ptr()), small.numel(), st1, 1, 2) != 0
+    assert "workspace too small for this group" in _lib.last_error()
+    ed = sesrq.Engine(b, _dev(), engine=_lib.ENGINE_DOT4)
+    assert _lib.lib().sesrq_forward_many(ed._h, io2, 4, _lib.F32, 1, 45, 130, (C.c_void_p * 1)(big.data_ptr()), big.numel(), st1, 1, 2) != 0
+    assert "MFMA first- and last-layer kernels" in _lib.last_error()
 
 
 @pytest.mark.gpu

@@ -117,3 +117,34 @@ def test_engine_refuses_without_gpu():
     from helpers import bundle_from_oracle
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         sesrq.Engine(bundle_from_oracle(O.synth_net("nrdm", 0)))
+
+
+def test_submission_pool_survives_fork():
+    """Round 5: the pool of sesrq_forward_many is per process.  A child forked AFTER the parent's pool has threads gets a working pool of
+    its own on its first call (pthread_atfork drops the parent's objects: round 4's child published jobs to threads that do not exist in
+    it and spun forever) -- no device needed: sesrq_submit_selftest drives the same hand-off with jobs that only count themselves."""
+    import signal
+    lib = _lib.lib()
+    assert lib.sesrq_submit_selftest(4, 50) == 200          # the parent's pool has three threads now
+    pid = os.fork()
+    if pid == 0:
+        signal.alarm(20)                                     # a hang in the child must not hang the test session
+        ok = lib.sesrq_submit_selftest(4, 50) == 200 and lib.sesrq_submit_selftest(6, 5) == 30
+        os._exit(0 if ok else 1)
+    _, status = os.waitpid(pid, 0)
+    assert os.WIFEXITED(status) and os.WEXITSTATUS(status) == 0, f"forked child: status {status:#x}"
+    assert lib.sesrq_submit_selftest(4, 50) == 200          # and the parent's is untouched
+    assert lib.sesrq_submit_selftest(1, 1) == -1 and "n_streams" in _lib.last_error()
+
+
+def test_instance_registry_lists_every_kernel_family():
+    """The library enumerates the kernel instantiations it can launch (no device needed: filled when the library is loaded)."""
+    inst = _lib.instances()
+    fam = {}
+    for n in inst:
+        fam[n.split("<")[0]] = fam.get(n.split("<")[0], 0) + 1
+    for f in ("conv_dot4_kernel", "mfma_f5_kernel_w4", "mfma_f5_kernel", "mfma_h3_kernel", "mfma_h5_kernel", "mfma_h5p_kernel", "mfma_trio_kernel",
+              "unpack_nhwc16_kernel", "verify_fastdiv_kernel", "calib_conv_kernel", "calib_minmax_kernel", "calib_hist_kernel", "calib_fakequant_kernel"):
+        assert fam.get(f, 0) >= 1, (f, fam)
+    assert fam["mfma_trio_kernel"] == 9 and "mfma_trio_kernel<1, 15>" in inst and "mfma_h5_kernel<1, 2, 22, 3>" in inst
+    assert all(v == 0 for k, v in inst.items() if k.startswith("mfma_")), "nothing has been launched in a CPU session"

@@ -183,6 +183,11 @@ def test_dump_flags_write_an_output_pt_compatible_tree(case, tmp_path, monkeypat
         assert (STORE[f"requan_factor/requan_{k}_{k + 1}"], STORE[f"requan_factor/n_{k}_{k + 1}"]) == (meta["M"][k], meta["n"][k])
         np.testing.assert_array_equal(STORE[f"weight/conv.weight.{k}"].numpy(), fx[f"Wq{k}"].astype(np.float32))
     np.testing.assert_array_equal(STORE["input/input.5"].numpy(), fx["input5"].astype(np.float32))
+    # round 5: the two tensors the reference writes unconditionally (quan_func.py:549, :254) are part of the tree now
+    assert os.path.isfile(os.path.join(root, "residual", "shortcut_tensor.pt")) and os.path.isfile(os.path.join(root, "input", "input.4.spcial.pt"))
+    assert STORE["residual/shortcut_tensor"].dtype == torch.float32
+    np.testing.assert_array_equal(STORE["residual/shortcut_tensor"].numpy(), fx["shortcut"])
+    np.testing.assert_array_equal(STORE["input/input.4.spcial"].numpy(), fx["input4_special"].astype(np.float32))
     assert (STORE["requan_factor/requan_res"], STORE["requan_factor/n_res"]) == (meta["M_res"], meta["n_res"])
     STORE.clear()
 
@@ -362,28 +367,48 @@ def test_reference_float_checkpoint_gives_the_golden_int8_weights(ckpt, mflag, c
 
 
 def test_registered_torch_op_schema_and_fake_kernel():
-    """torch.ops.sesrq.forward is a registered operator: schema, shape inference through the fake kernel, one op
-    node in the lowered graph; no CPU kernel (the product path never falls back)."""
+    """torch.ops.sesrq.forward is a registered operator -- since round 5 registered in C++ (TORCH_LIBRARY in
+    csrc/torch_op/sesrq_torch_op.cpp, built with torch.utils.cpp_extension, linked against libsesrq.so): schema, shape inference through
+    the Meta kernel, one op node in the lowered graph; no CPU kernel (the product path never falls back).  No device needed: a shape-only
+    handle (a bundle without a device net) can be traced, not run."""
     from sesrq import torch_op
+    from sesrq.bundle import Bundle
+    ext = torch_op.extension()
+    assert os.path.basename(torch_op.EXT_PATH) == "sesrq_torch_op.so" and hasattr(ext, "sesrq_torch_register")
+    import subprocess
+    needed = subprocess.run(["readelf", "-d", torch_op.EXT_PATH], capture_output=True, text=True).stdout
+    assert "libsesrq.so" in needed and "libc10_hip.so" in needed, "the operator library links the C-ABI library and torch's HIP runtime layer"
 
-    class FakeEngine:                       # only what the fake kernel and the graph builder touch
-        def out_shape(self, N, H, W):
-            return (N, 3, 2 * H, 2 * W)
-    eng = FakeEngine()
+    class ShapeOnly:                        # what register_engine reads from an Engine: its bundle (and _h, absent here)
+        bundle = Bundle.load(os.path.join(GOLDEN, "sesr_x2_rand.crop.npz"))
+    eng = ShapeOnly()
     eid = torch_op.register_engine(eng)
-    assert str(torch.ops.sesrq.forward.default._schema) == "sesrq::forward(Tensor x, SymInt engine_id) -> (Tensor, Tensor)" or \
-        "sesrq::forward(Tensor x, int engine_id) -> (Tensor, Tensor)" in str(torch.ops.sesrq.forward.default._schema)
+    schema = str(torch.ops.sesrq.forward.default._schema)
+    assert schema in ("sesrq::forward(Tensor x, int engine_id) -> (Tensor, Tensor)", "sesrq::forward(Tensor x, SymInt engine_id) -> (Tensor, Tensor)"), schema
+    assert "forward_into(Tensor x, int engine_id, Tensor(a!)? out_q, Tensor(b!)? out_f, Tensor(c!) workspace) -> ()" in str(torch.ops.sesrq.forward_into.default._schema)
+    # the kernels are C++ functions, not Python callables: nothing of the op is registered from Python
+    assert torch._C._dispatch_has_kernel_for_dispatch_key("sesrq::forward", "CUDA") and torch._C._dispatch_has_kernel_for_dispatch_key("sesrq::forward", "Meta")
+    assert not torch._C._dispatch_has_kernel_for_dispatch_key("sesrq::forward", "CPU")
+    q, y = torch.ops.sesrq.forward(torch.empty(2, 3, 10, 12, device="meta"), eid)
+    assert tuple(q.shape) == (2, 3, 20, 24) and q.dtype == torch.int8 and y.dtype == torch.float32 and q.device.type == "meta"
     from torch._subclasses.fake_tensor import FakeTensorMode
     with FakeTensorMode():
         q, y = torch.ops.sesrq.forward(torch.empty(2, 3, 10, 12), eid)
         assert tuple(q.shape) == (2, 3, 20, 24) and q.dtype == torch.int8 and y.dtype == torch.float32
+    with pytest.raises(ValueError, match="Expect input tensor dimension: 4"):
+        torch.ops.sesrq.forward(torch.empty(3, 10, 12, device="meta"), eid)
+    with pytest.raises(ValueError, match="expected 3 input channels"):
+        torch.ops.sesrq.forward(torch.empty(1, 1, 10, 12, device="meta"), eid)
     gm = torch_op.lowered_module(eng)
     ops = [n for n in gm.graph.nodes if n.op == "call_function" and n.target is torch.ops.sesrq.forward.default]
     assert len(ops) == 1 and len([n for n in gm.graph.nodes if n.op == "call_function"]) == 2      # the op + getitem
     with pytest.raises((NotImplementedError, RuntimeError)):
         torch.ops.sesrq.forward(torch.zeros(1, 3, 4, 4), eid)                 # CPU tensor: no kernel
     with pytest.raises(RuntimeError, match="not registered"):
-        torch_op._engine(10 ** 9)
+        torch.ops.sesrq.forward(torch.empty(1, 3, 4, 4, device="meta"), 10 ** 9)
+    torch_op.unregister_engine(eng)
+    with pytest.raises(RuntimeError, match="not registered"):
+        torch.ops.sesrq.forward(torch.empty(1, 3, 4, 4, device="meta"), eid)
 
 
 @pytest.mark.gpu
