@@ -121,10 +121,12 @@ def main():
     ap.add_argument("--engine", default="auto", choices=["auto", "dot4", "mfma"])
     ap.add_argument("--no-fuse", action="store_true", help="one launch per layer (no fused hidden trio)")
     ap.add_argument("--fuse", type=int, default=1, choices=[0, 1], help="0 per layer, 1 (default) fused hidden trios")
-    ap.add_argument("--submit", default="auto", choices=["auto", "many", "step"],
+    ap.add_argument("--submit", default="auto", choices=["auto", "many", "step", "op"],
                     help="how the steps reach the library: 'step' = one sesrq_forward per step from Python; 'many' = sesrq_forward_many, all the steps "
                          "of a block handed over by ONE call (the C side loops over the frames and streams): the same kernels, launches and "
-                         "buffers, only the host's per-step cost changes.  auto = many for a single net without --graph, else step")
+                         "buffers, only the host's per-step cost changes; 'op' = one torch.ops.sesrq.forward_into per step (the C++-registered operator, "
+                         "csrc/torch_op/sesrq_torch_op.cpp: dispatcher -> current HIP stream -> sesrq_forward, no Python in between).  auto = many for a "
+                         "single net without --graph, else step")
     ap.add_argument("--wg-budget", type=int, default=-1,
                     help="workgroup slots a launch may fill (sesrq_options.wg_budget; 0 = one full round of the chip).  -1 = the workload's "
                          "tuned plan (PLAN): two slots per compute unit (512 of an MI355X's 1024) for the single-frame workloads, so that kernels of three "
@@ -136,6 +138,7 @@ def main():
     ap.add_argument("--blocking-sync", action="store_true", help="fence with the blocking torch.cuda.synchronize() only")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-e2e", action="store_true")
+    ap.add_argument("--no-boundary-legs", action="store_true", help="skip the fp32-output / anchor-add throughput legs (boundary_return)")
     args = ap.parse_args()
 
     if args.repeats <= 0:
@@ -152,13 +155,24 @@ def main():
                "--master-addr", "127.0.0.1", "--master-port", str(29500 + os.getpid() % 2000), os.path.abspath(__file__)] + sys.argv[1:]
         sys.exit(subprocess.run(cmd).returncode)
 
+    # One rank = one GPU = one slice of the node's CPUs (round 5): pinned before torch and the library start their threads.  Where ranks
+    # outnumber a quarter of the cores nothing may busy-wait: the library's submission threads sleep at once (SESRQ_SPIN_US=0, read when the
+    # library is loaded) and the fence's event spin yields.
+    from sesrq.dist import Group, env_world, oversubscribed, pin_rank_cpus, run_timed, shard
+    rank, local, world = env_world()
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
+    cpus = pin_rank_cpus(local, local_world) if world > 1 else sorted(os.sched_getaffinity(0))
+    yielding = oversubscribed(local_world if world > 1 else 1, cpus if world == 1 else None)
+    if yielding:
+        os.environ.setdefault("SESRQ_SPIN_US", "0")
     import numpy as np
     import torch
+    # The timing fence: ALWAYS a gloo group first, created before this process touches the GPU; RCCL ("nccl") is tried on top of it once
+    # the device is set and used only if every rank gets through (sesrq/dist.py) -- the data path has no collective to lose.
+    grp = Group(backend=args.dist_backend)
     import sesrq
     from sesrq import _lib
     from sesrq.bundle import Bundle
-    from sesrq.dist import Group, env_world, run_timed, shard
-    rank, local, world = env_world()
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device")
     if args.share_gpu:
@@ -167,8 +181,7 @@ def main():
     dev = torch.device(f"cuda:{local}")
     if args.wg_budget < 0:
         args.wg_budget = plan_slots_per_cu * torch.cuda.get_device_properties(dev).multi_processor_count
-    # RCCL ("nccl") on a multi-GPU node; only the timing fence uses it.  gloo reduces on the host.
-    grp = Group(backend=args.dist_backend, device=dev if args.dist_backend == "nccl" else None)
+    grp.bind_device(dev)
 
     fixtures, cin, H, W, (mode, nframes), desc = WORKLOADS[args.workload]
     bundles = [Bundle.load(os.path.join(ROOT, "tests", "golden", f)) for f in fixtures]
@@ -229,6 +242,17 @@ def main():
         sub.enqueue(n, first=counter[0])
         counter[0] += n
 
+    op_ids, op_ws = [], []
+    if args.submit == "op":
+        from sesrq import torch_op
+        op_ids = [getattr(e, "_op_id", None) or torch_op.register_engine(e) for e in engines]
+        n_, h_, w_ = max(B, 1), H, W
+        dims = []
+        for e in engines:
+            dims.append((n_, h_, w_))
+            shp_ = e.out_shape(n_, h_, w_)
+            h_, w_ = shp_[2], shp_[3]
+        op_ws = [[e.workspace(*dims[j], sl) for j, e in enumerate(engines)] for sl in range(NS)]
     graphs = {}
     if args.graph and B > 0:       # one graph per (stream slot, pool frame): the input pointer is part of a graph
         for slot in range(NS):
@@ -241,6 +265,13 @@ def main():
         if B > 0 and graphs:
             with torch.cuda.stream(streams[i % NS]):
                 graphs[(i % NS, i % POOL)].replay()
+        elif B > 0 and args.submit == "op":
+            sl = i % NS
+            with torch.cuda.stream(streams[sl]):
+                cur = pool[i % POOL]
+                for j, eid in enumerate(op_ids):
+                    torch.ops.sesrq.forward_into(cur, eid, outs[sl][j], None, op_ws[sl][j])
+                    cur = outs[sl][j]
         elif B > 0:
             forward_chain(pool[i % POOL], i % NS, streams[i % NS])
 
@@ -261,6 +292,24 @@ def main():
                 gq, _ = graphs[(0, 0)].replay()
             torch.cuda.synchronize()
             got = gq[0:1].cpu().numpy()
+        elif sub is not None:
+            # what is timed is sesrq_forward_many (submission threads, and for the 540p workloads grouped pointer-table launches):
+            # THAT path's output is what is compared.  One launch sequence per stream (NS x G frames: no buffer is written twice), frame 0's
+            # buffer against the C oracle / the reference's SHA below, every other buffer against a one-stream sesrq_forward of its frame.
+            nfirst = NS * sub.group
+            for t in sub._keep[1]:
+                t.zero_()
+            torch.cuda.synchronize()
+            sub.enqueue(nfirst)
+            torch.cuda.synchronize()
+            got = sub._keep[1][0][0:1].cpu().numpy()
+            many_checked, many_bad = 0, 0
+            for i in range(1, nfirst):
+                q1, _ = engines[0].forward(pool[i % POOL], want_f=False)
+                torch.cuda.synchronize()
+                many_checked += 1
+                many_bad += int(not torch.equal(q1, sub._keep[1][i]))
+            counter[0] = nfirst      # the rotation goes on where this left it
         else:
             got = forward_chain(pool[0], 0, torch.cuda.current_stream(dev))[0:1].cpu().numpy()
         torch.cuda.synchronize()
@@ -277,9 +326,14 @@ def main():
         want = cur
         diff = got.astype(np.int32) - want.astype(np.int32)
         maxdiff = int(np.abs(diff).max())
-        parity = {"checked": f"full frame ({'x'.join(map(str, got.shape))}) of pool frame 0 vs C oracle", "max_abs_diff_int8": maxdiff,
+        path = ("HIP-graph replay" if graphs else (f"sesrq_forward_many ({NS} streams, {sub.group} frame(s) per launch sequence: the timed path)" if sub is not None
+                                                    else "sesrq_forward per step (the timed path)"))
+        parity = {"checked": f"full frame ({'x'.join(map(str, got.shape))}) of pool frame 0 through {path} vs C oracle", "max_abs_diff_int8": maxdiff,
                   "mismatches": int((diff != 0).sum()),
                   "psnr_db": "inf" if maxdiff == 0 else float(10 * np.log10(255.0 ** 2 / np.mean(diff.astype(np.float64) ** 2)))}
+        if sub is not None and not graphs:
+            parity["other_frames_of_the_timed_path"] = {"checked": many_checked, "differ_from_one_stream_forward": many_bad}
+            parity["mismatches"] += many_bad
         # headline workload: pool frame 0 of rank 0 is the very frame the REFERENCE itself was run on in the build container
         # (tests/golden/reference_x2_1080p.json): the whole int8 4K frame against the reference's own output, by SHA-256
         rf = os.path.join(ROOT, "tests", "golden", "reference_x2_1080p.json")
@@ -308,7 +362,8 @@ def main():
             for e, st in zip(fence_events, streams):
                 e.record(st)
             while not all(e.query() for e in fence_events):
-                pass
+                if yielding:
+                    os.sched_yield()
         torch.cuda.synchronize()
 
     res = run_timed(grp, step, args.steps, args.warmup, repeats=args.repeats, sync=drain, units_per_step=B, step_many=step_many if sub else None)
@@ -371,6 +426,13 @@ def main():
                             "the committed profile of the same kernel is under from_committed_profile; layerwise_frac = SURVEY "
                             "8(d)'s layer-by-layer bytes per frame x frames/s/GPU / peak = the north star's HBM-roofline fraction"}
 
+        # ---- the boundary's own return type (never `value`): the reference's model(inps) returns the fp32 frame (quan_func.py:594), its eval
+        # loop adds the nearest-upsampled input to the x2 result (test.py:148-155).  Same plan, same pool, fp32 frame out (4 x the output bytes).
+        boundary = None
+        if world == 1 and len(engines) == 1 and B > 0 and not args.no_boundary_legs:
+            boundary = boundary_legs(torch, np, sesrq, bundles[0], ekw, dev, pool, streams, args, drain, H, W, fps,
+                                     launch_bytes_per_px, plan, want, onets[0])
+
         # ---- end to end through pinned host buffers (never `value`): H2D / compute / D2H on three streams
         e2e = None
         if world == 1 and not args.no_e2e and B > 0:
@@ -382,11 +444,13 @@ def main():
                   "ms_per_step": round(elapsed_med / args.steps * 1e3, 5), "higher_is_better": True,
                   "scaling": "strong" if mode == "total" else "weak",
                   "vs_baseline": None, "dtype": "i8", "data": "synthetic",
+                  "fence": grp.fence, "host": {"cpus_of_rank0": len(cpus), "ranks_on_node": local_world, "busy_wait": "yield" if yielding else "spin"},
                   "host_enqueue_us_per_step": None if res["host_enqueue_s_per_step"] is None else round(res["host_enqueue_s_per_step"] * 1e6, 1),
                   "host_enqueue_sample_steps": res["host_enqueue_sample_steps"], "repeats": args.repeats, "blocks_fps": [round(args.steps * total_frames_per_step / e, 1) for e in res["elapsed"]], "spread": {"min": round(fps_all[0], 2), "median": round(fps, 2), "max": round(fps_all[-1], 2)},
                   "config": {"workload": desc, "name": args.workload, "frames_per_step_per_gpu": B, "frames_per_step": total_frames_per_step,
                              "streams": NS, "wg_budget": args.wg_budget, "hip_graph": bool(graphs),
-                             "submit": (f"sesrq_forward_many: one call per timed block of K steps, up to {sub.group} frame(s) of a stream per launch sequence" if sub else "sesrq_forward per step"), "input_pool": f"{POOL} distinct resident frames, rotated per step",
+                             "submit": (f"sesrq_forward_many: one call per timed block of K steps, up to {sub.group} frame(s) of a stream per launch sequence" if sub else
+                                        ("torch.ops.sesrq.forward_into per step (C++ operator)" if args.submit == "op" else "sesrq_forward per step")), "input_pool": f"{POOL} distinct resident frames, rotated per step",
                              "in": [B, cin, H, W], "out": list(shapes[-1]), "input_dtype": "f32", "output_dtype": "i8",
                              "weights": [("reference random-init net, calibrated by the reference" if "rand" in f else
                                           "reference checkpoint, calibrated by this package (parity unpinned)" if "bundle" in f else
@@ -394,10 +458,75 @@ def main():
                              "sharding": f"frames over {world} rank(s), contiguous blocks, no collective",
                              "launch_plan": [[names[f], c] for f, c in plan], "engines": [e.layer_engines() for e in engines],
                              "requant_forms": [e.one_fma_layers() for e in engines]},      # per layer: 1 / 2 = a load-time proof let the kernels run a reduced form
-                  "roofline": roofline, "cpu_baseline": cpu, "e2e": e2e, "parity": parity}
+                  "roofline": roofline, "cpu_baseline": cpu, "boundary_return": boundary, "e2e": e2e, "parity": parity}
     grp.close()
     if result is not None:
         print(json.dumps(result), flush=True)
+
+
+def boundary_legs(torch, np, sesrq, bundle, ekw, dev, pool, streams, args, drain, H, W, fps_int8, launch_bytes_per_px, plan, want_q0, onet):
+    """Frames/s with the boundary's REAL return type (never `value`): (1) fp32 frame out only -- what the reference's
+    model(inps) returns, (q - zero_L) * f32(scale_L) (quan_func.py:594) -- and (2) fp32 out with the x2 anchor add of the reference's eval
+    loop (test.py:148-155: gfake + inps_x2; nets with Cin * r^2 == Cout only).  Same launch plan, pool and streams as the headline, the steps
+    handed over by sesrq_forward_many; median of up to 15 blocks of --steps steps.  Whole-frame parity of pool frame 0: the fp32 frame must
+    be the one rounding of the int8 frame the parity leg has already checked (and, on the headline workload, hash to the reference's own
+    out_f_sha256); the anchored frame must equal that plus the nearest-upsampled input, one fp32 add."""
+    import hashlib
+    import math
+    import statistics
+    r = bundle.pixel_shuffle
+    NS = len(streams)
+    period = len(pool) * NS // math.gcd(len(pool), NS)
+    B = pool[0].shape[0]
+    px = B * H * W
+    cout_last = int(bundle.layers[-1].wq.shape[0])
+    out = {}
+    legs = [("fp32_out", False)]
+    if bundle.in_channels * r * r == cout_last:
+        legs.append(("fp32_out_anchor_add", True))
+    rf = os.path.join(ROOT, "tests", "golden", "reference_x2_1080p.json")
+    ref = json.load(open(rf)) if (args.workload == "sesr_x2_1080p" and os.path.isfile(rf)) else None
+    for name, anchor in legs:
+        e = sesrq.Engine(bundle, dev, anchor_add=anchor, **ekw)
+        shp = e.out_shape(B, H, W)
+        of = [torch.empty(shp, dtype=torch.float32, device=dev) for _ in range(NS)]
+        sub = e.submission([pool[i % len(pool)] for i in range(period)], None, streams, outs_f=[of[i % NS] for i in range(period)])
+        sub.enqueue(1)
+        torch.cuda.synchronize()
+        y0 = of[0][0:1].cpu().numpy()
+        rec = {"unit": "frames/s", "output_dtype": "f32", "anchor_add": anchor}
+        if want_q0 is not None:
+            yq = ((want_q0.astype(np.float32) - np.float32(onet.zero[onet.L])) * np.float32(onet.scale[onet.L])).astype(np.float32)
+            if anchor:
+                x0 = pool[0][0:1].cpu().numpy()
+                yq = (yq + np.repeat(np.repeat(x0, r, axis=2), r, axis=3)).astype(np.float32)      # gfake + inps_x2 (test.py:148-155)
+            rec["parity"] = {"checked": f"full fp32 frame ({'x'.join(map(str, y0.shape))}) of pool frame 0 vs the C oracle's int8 frame dequantised"
+                                        + (" + nearest-upsampled input" if anchor else ""), "mismatches": int((y0 != yq).sum())}
+            if ref is not None and not anchor:
+                rec["parity"]["reference_out_f_sha256_match"] = hashlib.sha256(np.ascontiguousarray(y0).tobytes()).hexdigest() == ref["out_f_sha256"]
+        done = 1
+        sub.enqueue(max(args.warmup, 1), first=done)
+        done += max(args.warmup, 1)
+        drain()
+        els = []
+        for _ in range(min(args.repeats, 15)):
+            t0 = time.perf_counter()
+            sub.enqueue(args.steps, first=done)
+            drain()
+            els.append(time.perf_counter() - t0)
+            done += args.steps
+        el = statistics.median(els)
+        v = args.steps * B / el
+        # bytes as launched: the last launch writes 4 bytes per output value instead of 1 (and re-reads the fp32 input frame for the anchor)
+        bpp = [launch_bytes_per_px(bundle, f, c, True) for f, c in plan]
+        bpp[-1] += 3 * cout_last + (4 * bundle.in_channels if anchor else 0)
+        rec.update(value=round(v, 2), ms_per_step=round(el / args.steps * 1e3, 5), vs_int8_out=round(v / fps_int8, 4),
+                   bytes_per_frame_as_launched=int(sum(bpp) * px / B), throughput_frac=round(sum(bpp) * px / B * v / HBM_PEAK, 4))
+        out[name] = rec
+        e.close()
+    out["note"] = ("the reference's model(inps) returns the fp32 frame (myQL/quan_func.py:594); its eval loop adds the nearest-upsampled input to the x2 "
+                   "result (test.py:148-155).  Same plan / pool / streams as `value`, which writes the int8 frame (SURVEY 8d's end points); never `value`")
+    return out
 
 
 def e2e_leg(torch, engines, pool, outs, B, frames=96, depth=3, int8_in=False):

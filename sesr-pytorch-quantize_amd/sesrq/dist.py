@@ -75,58 +75,128 @@ def run_timed(group: "Group", step, steps: int, warmup: int, repeats: int = 1, s
             "rates": [steps * total_units / e for e in elapsed], "host_enqueue_s_per_step": host_s, "host_enqueue_sample_steps": HOST_SAMPLE}
 
 
+def rank_cpus(local_rank: int, local_world: int, cpus=None):
+    """The contiguous slice of this process's allowed CPUs that belongs to `local_rank` of `local_world` ranks on the node (slices are
+    disjoint and cover the set); fewer CPUs than ranks: everyone keeps the whole set."""
+    cpus = sorted(os.sched_getaffinity(0)) if cpus is None else sorted(cpus)
+    n = len(cpus)
+    if local_world <= 1 or n < local_world:
+        return cpus
+    return cpus[local_rank * n // local_world:(local_rank + 1) * n // local_world]
+
+
+def oversubscribed(local_world: int, cpus=None) -> bool:
+    """Fewer than four CPUs per rank: busy-waiting threads (the submission pool's workers, the fence's event spin) would take cores from
+    each other's enqueue threads -- they must yield instead (SESRQ_SPIN_US=0, os.sched_yield())."""
+    n = len(os.sched_getaffinity(0)) if cpus is None else len(cpus)
+    return n < 4 * max(1, local_world)
+
+
+def pin_rank_cpus(local_rank: int, local_world: int):
+    """Pin this process (and every thread it starts afterwards: torch's, the library's submission threads) to its slice of the node's CPUs.
+    One rank per GPU each spins on its own streams; without a pin, eight ranks' enqueue threads migrate over each other.  Returns the slice."""
+    mine = rank_cpus(local_rank, local_world)
+    try:
+        os.sched_setaffinity(0, mine)
+    except OSError:
+        pass
+    return mine
+
+
 class Group:
-    """Thin wrapper over torch.distributed used by bench.py; a no-op for world_size 1."""
+    """Thin wrapper over torch.distributed used by bench.py; a no-op for world_size 1.
+
+    Round 5: the measurement fence cannot be lost to RCCL.  The process group is ALWAYS gloo first (host-only: created before the process has
+    touched the GPU); backend "nccl" (= RCCL) is then TRIED as a second group once the device is known (bind_device) -- communicator, one
+    all-reduce, agreement of all ranks over the gloo group -- and used for the fence only if every rank succeeded.  Otherwise the cause is
+    printed once, the gloo fence stays, and `fence` says so ("gloo (nccl: <error>)"): the data path never crosses devices, so a scaling run
+    must not end with exit 3 because a collective library could not start (rounds 3-4 did)."""
 
     def __init__(self, backend: Optional[str] = None, device=None, timeout_s: Optional[float] = None, force: bool = False):
         """force: build the process group at world size 1 too (the one-GPU box's way to run the RCCL fence: communicator creation,
         barrier, MAX / SUM all-reduce on the device -- tests/test_00_bench_spawn.py)"""
         self.rank, self.local_rank, self.world = env_world()
         self.dist = None
-        self.device = device
+        self.pg = None              # the group the fence runs on (None = the default gloo group)
+        self.device = None          # device of the reduction tensors (None = host)
+        self.fence = "none (one process)"
+        self.want = backend or "nccl"
+        self.timeout_s = timeout_s
         if self.world > 1 or force:
             import torch.distributed as dist
             kw = {}
-            if backend == "nccl" and device is not None:
-                kw["device_id"] = device
             if timeout_s is not None:
                 import datetime
                 kw["timeout"] = datetime.timedelta(seconds=timeout_s)
             try:
-                dist.init_process_group(backend or "nccl", **kw)
-            except Exception as exc:      # RCCL not usable on this box (no device, IPC refused, rendezvous failed ...)
-                # A clean non-zero exit with the cause: the launcher (torchrun / the driver) sees rank failure at once.  Never a re-exec:
-                # this process may have initialised the GPU already.
+                dist.init_process_group("gloo", **kw)
+            except Exception as exc:      # no rendezvous at all (MASTER_ADDR / port): nothing to fall back to
                 import sys
-                print(f"sesrq.dist: init_process_group(backend={backend or 'nccl'!r}, rank {self.rank} of {self.world}, "
-                      f"MASTER_ADDR={os.environ.get('MASTER_ADDR')}:{os.environ.get('MASTER_PORT')}) failed: {type(exc).__name__}: {exc}\n"
-                      "sesrq.dist: the data path needs no collective (frames shard, bundle replicated); only the timing fence does -- "
-                      "rehearse with --dist-backend gloo, or fix the RCCL setup (HSA_ENABLE_IPC_MODE_LEGACY=0, one rank per GPU)", file=sys.stderr, flush=True)
+                print(f"sesrq.dist: init_process_group('gloo', rank {self.rank} of {self.world}, "
+                      f"MASTER_ADDR={os.environ.get('MASTER_ADDR')}:{os.environ.get('MASTER_PORT')}) failed: {type(exc).__name__}: {exc}", file=sys.stderr, flush=True)
                 raise SystemExit(3)
             self.dist = dist
+            self.fence = "gloo"
+            if device is not None:
+                self.bind_device(device)
+
+    def bind_device(self, device, probe_timeout_s: float = 120.0):
+        """Try the device backend (RCCL) for the fence now that the rank's device is set.  Never raises, never exits: on any failure on any
+        rank every rank keeps the gloo fence."""
+        if self.dist is None or self.want != "nccl":
+            return self.fence
+        import datetime
+        import torch
+        dist = self.dist
+        os.environ.setdefault("TORCH_NCCL_ASYNC_ERROR_HANDLING", "0")      # a failed probe must not take the process down
+        err, pg = None, None
+        try:
+            if os.environ.get("SESRQ_FORCE_NCCL_FAILURE"):                   # test hook: tests/test_dist_gloo.py
+                raise RuntimeError("SESRQ_FORCE_NCCL_FAILURE is set")
+            pg = dist.new_group(backend="nccl", timeout=datetime.timedelta(seconds=self.timeout_s or probe_timeout_s), device_id=device)
+            t = torch.ones(1, dtype=torch.float64, device=device)
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=pg)
+            if int(t.item()) != dist.get_world_size():
+                raise RuntimeError(f"all-reduce over RCCL returned {t.item()} for {dist.get_world_size()} ranks")
+        except Exception as exc:
+            err = f"{type(exc).__name__}: {str(exc).splitlines()[0][:200] if str(exc) else ''}"
+        # agreement over the group that works: RCCL is used only if EVERY rank got through
+        ok = torch.tensor([0.0 if err else 1.0], dtype=torch.float64)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if ok.item() == 1.0:
+            self.pg, self.device, self.fence = pg, device, "nccl"
+        else:
+            import sys
+            why = err or "another rank failed"
+            print(f"sesrq.dist: rank {self.rank}: the RCCL fence is not available ({why}); keeping the gloo fence -- the data path needs no "
+                  "collective (frames shard, bundle replicated), only the timing fence does", file=sys.stderr, flush=True)
+            self.fence = f"gloo (nccl: {why})"
+        return self.fence
 
     def barrier(self):
         if self.dist is not None:
-            self.dist.barrier()
+            if self.pg is not None:
+                self.dist.barrier(group=self.pg)
+            else:
+                self.dist.barrier()
+
+    def _reduce(self, value: float, op) -> float:
+        import torch
+        t = torch.tensor([float(value)], dtype=torch.float64, device=self.device if self.device is not None else "cpu")
+        if self.pg is not None:
+            self.dist.all_reduce(t, op=op, group=self.pg)
+        else:
+            self.dist.all_reduce(t, op=op)
+        return float(t.item())
 
     def max_over_ranks(self, value: float) -> float:
-        if self.dist is None:
-            return float(value)
-        import torch
-        t = torch.tensor([float(value)], dtype=torch.float64, device=self.device if self.device is not None else "cpu")
-        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
-        return float(t.item())
+        return float(value) if self.dist is None else self._reduce(value, self.dist.ReduceOp.MAX)
 
     def sum_over_ranks(self, value: float) -> float:
-        if self.dist is None:
-            return float(value)
-        import torch
-        t = torch.tensor([float(value)], dtype=torch.float64, device=self.device if self.device is not None else "cpu")
-        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
-        return float(t.item())
+        return float(value) if self.dist is None else self._reduce(value, self.dist.ReduceOp.SUM)
 
     def close(self):
         if self.dist is not None:
-            self.dist.barrier()
+            self.barrier()
             self.dist.destroy_process_group()
             self.dist = None

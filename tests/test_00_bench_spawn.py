@@ -30,6 +30,7 @@ def test_bench_two_ranks_spawned_by_the_launcher():
     assert d["scaling"] == "weak" and d["value"] > 0
     assert d["parity"]["mismatches"] == 0 and d["parity"]["max_abs_diff_int8"] == 0
     assert d["cpu_baseline"] is None and d["e2e"] is None      # rank-0-at-N=1-only legs
+    assert d["fence"] == "gloo" and d["host"]["ranks_on_node"] == 2
 
 
 @pytest.mark.gpu
@@ -46,10 +47,30 @@ def test_rccl_fence_on_a_one_rank_group():
             "r = run_timed(g, lambda: x.add_(1), steps=4, warmup=1, repeats=2, sync=torch.cuda.synchronize, units_per_step=3)\n"
             "assert r['units_per_step_total'] == 3 and len(r['elapsed']) == 2 and g.max_over_ranks(1.5) == 1.5\n"
             "assert float(x[0]) == 1 + 16 + 8\n"
-            "import torch.distributed as d; print('backend', d.get_backend(), flush=True); g.close()") % os.path.join(ROOT, "sesr-pytorch-quantize_amd")
+            "import torch.distributed as d; print('backend', d.get_backend(g.pg), 'fence', g.fence, flush=True); g.close()") % os.path.join(ROOT, "sesr-pytorch-quantize_amd")
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=env)
     assert r.returncode == 0, r.stderr[-3000:]
-    assert "backend nccl" in r.stdout
+    assert "backend nccl fence nccl" in r.stdout
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_keep_a_fence_when_rccl_cannot_start():
+    """Round 5: the DEFAULT backend (nccl) with two ranks on the one device -- RCCL refuses two ranks on one GPU, i.e. a real failure of the
+    real library on the real box: the run must still end with rc 0, ONE JSON line, parity 0 and `fence` = "gloo (nccl: ...)"."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--share-gpu", "--steps", "5",
+           "--warmup", "2", "--repeats", "2", "--no-cpu-baseline", "--no-e2e", "--timing-iters", "5"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["parity"]["mismatches"] == 0 and d["value"] > 0
+    assert d["fence"].startswith("gloo (nccl: ") or d["fence"] == "nccl", d["fence"]
+    if d["fence"] != "nccl":
+        assert "the RCCL fence is not available" in r.stderr
 
 
 @pytest.mark.gpu
