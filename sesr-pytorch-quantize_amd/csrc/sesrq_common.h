@@ -169,6 +169,8 @@ struct ConvArgs {
     int *dbg_ovf;            // [2] counters: PE sums above / below the accumulator range before saturation, or NULL (dot4 general kernels only)
     int N, H, W;
     int chunk_tiles;         // mfma engine: vertically adjacent tiles walked by one workgroup
+    int run_q, run_rem;      // mfma engine: run y of the strip covers tiles [y * run_q + min(y, run_rem), ... + run_q + (y < run_rem)): the host's division
+    unsigned inv_nx;         // ceil(2^32 / gridDim.x) for xcd_block's block -> (strip, run) split without a division, or 0 (grid too large: divide)
     int wg_budget;           // mfma engine: workgroup slots the launch may fill (0 = one round of the chip)
     int ic, oc;              // real channel counts
     int pad_word;            // zc replicated into 4 bytes
@@ -206,6 +208,8 @@ struct TrioArgs {
     int N, H, W;
     int chunk_steps;         // 8-row steps per run, rounded up
     int run_unit;            // trio: rows per partition unit of the vertical runs, 8 (whole steps) or 4 (half steps)
+    int run_q, run_rem;      // run y of a strip covers units [y * run_q + min(y, run_rem), ... + run_q + (y < run_rem)) (the host's division)
+    unsigned inv_nx;         // as ConvArgs::inv_nx
     int wg_budget;           // workgroup slots the launch may fill (0 = one round of the chip)
     int allow;               // sesrq_options.reduced_forms: which proven reduced forms the launch may select (bits 1, 2, 4, 8)
     int pad_in;              // pad word of the first layer's input

@@ -93,9 +93,52 @@ struct LastStore {
     // pair map of last_slot_oc (12 channels, PixelShuffle(2)): bytes 0, 1 = one 2-byte run, byte 2 = a single.
     // FASTD = FAST + 10: the same with the one-fma requant (ConvArgs::direct: zero point -128, (M, n) proven): cvt_pk_u8 does clamp,
     // rounding and byte insertion -- per row 1 pk_fma + 1 fma + 3-4 cvt + 1 xor instead of 2 + 2 fma, 3-4 med3, 2 add, 1-3 perm
-    template <bool BIASED, int FASTD = 0, int NV = 4>
+    // OUTF (round 5, FAST flavours only): the fp32 frame INSTEAD of the int8 one -- what the reference's model(inps) returns, y = (q - zero_L) *
+    // f32(scale_L) (quan_func.py:594) -- with the same run structure as the int8 flavours: one 8-byte store per 2-value run, one 16-byte
+    // store per 4-value run (the every-output-kind path issues one dword store per value behind output-kind branches: 66 us per 1080p
+    // frame, 1.5 TB/s).  No anchor add here (that keeps the general path).
+    template <bool BIASED, int FASTD = 0, int NV = 4, bool OUTF = false>
     __device__ __forceinline__ void store(const int s[4], const ConvArgs &a, int gy, float zlo, bool row_ok = true) const {
         constexpr int FAST = FASTD % 10;
+        static_assert(!OUTF || FAST != 0, "fp32-only store: FAST flavours");
+        if constexpr (OUTF) {
+            float yv[4] = {0.f, 0.f, 0.f, 0.f};
+            const float sv = in_vgpr(a.s_out);
+            if constexpr (FASTD >= 10) {
+                // one-fma forms (zero_L == -128): q + 128 = clamp(rint(t), 0, 255) -- cvt_pk_u8's semantics, as a float -- IS q - zero_L
+                const float cv = in_vgpr(FASTD >= 20 ? a.Cs : a.Cd), mv = in_vgpr(a.Md), hi = in_vgpr(255.f);
+#pragma unroll
+                for (int i = 0; i < NV; ++i) {
+                    float t = __builtin_fmaf(__builtin_bit_cast(float, s[i]), mv, cv);
+                    if constexpr (FASTD >= 20) t = __fadd_rn(t, 128.f);
+                    yv[i] = __fmul_rn(__builtin_rintf(med3(t, 0.f, hi)), sv);
+                }
+            } else {
+                v2f v01, v23;
+                const int s3[4] = {s[0], s[1], s[2], NV == 4 ? s[3] : s[2]};
+                requant4<BIASED>(s3, a.Mf, a.sh, a.z_out, v01, v23);
+                const float v[4] = {v01[0], v01[1], v23[0], v23[1]};
+                const float zo = in_vgpr(a.z_out);
+#pragma unroll
+                for (int i = 0; i < NV; ++i) yv[i] = __fmul_rn(__fsub_rn(__builtin_rintf(med3(v[i], zlo, 127.f)), zo), sv);
+            }
+            const int so = __builtin_amdgcn_readfirstlane(row_ok ? gy * (FAST * FAST * a.W) * 4 : 0x7fff0000);
+            typedef float v2fs __attribute__((ext_vector_type(2)));
+            typedef float v4fs __attribute__((ext_vector_type(4)));
+            if constexpr (NV == 3) {
+                static_assert(FAST == 2, "three real rows per lane group: the PixelShuffle(2) pair map only");
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u, (v2fs){yv[0], yv[1]}), rf, this->vo[0] * 4, so, 0);
+                __builtin_amdgcn_raw_buffer_store_b32(fbits(yv[2]), rf, this->vo[2] * 4, so, 0);
+            } else if constexpr (FAST == 2) {
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u, (v2fs){yv[0], yv[1]}), rf, this->vo[0] * 4, so, 0);
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u, (v2fs){yv[2], yv[3]}), rf, this->vo[2] * 4, so, 0);
+            } else {
+                // 16-byte store: the row offset rides in the VECTOR offset, soffset = 0 (the store-data hazard of dwordx4 stores with an SGPR
+                // soffset: store_rows4, sesrq_mfma_common.h -- the grouped-launch test caught 16 garbage floats per frame with the scalar form)
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, (v4fs){yv[0], yv[1], yv[2], yv[3]}), rf, this->vo[0] * 4 + so, 0, 0);
+            }
+            return;
+        }
         if constexpr (FASTD >= 10) {
             static_assert(BIASED && FAST != 0, "one-fma requant: biased sums, int8 output");
             // FASTD 2x (ConvArgs::direct == 2): the fma also subtracts the 128 (one rounding of s*M*2^-n - 128), one add brings it back
@@ -338,9 +381,9 @@ struct StageNHWC16 {
 // prologue waits for arrives beside them instead of in front of them (round 4: 2 us from kernel entry to the first frame load of the last
 // layer, most of it dependent round trips to memory)
 #define SESRQ_TILE_WALK_BEGIN(TILE_H, STAGE_T)                                                      \
-    const int row_tiles_ = (a.H + (TILE_H) - 1) / (TILE_H);      /* runs of (almost) equal length */ \
-    const int t_begin = (int)(((long long)bxy.y * row_tiles_) / gridDim.y);                         \
-    const int t_end = (int)(((long long)(bxy.y + 1) * row_tiles_) / gridDim.y);                     \
+    /* runs of (almost) equal length: the first run_rem runs are one tile longer (the host divided: launch()) */ \
+    const int t_begin = bxy.y * a.run_q + min(bxy.y, a.run_rem);                                    \
+    const int t_end = t_begin + a.run_q + (bxy.y < a.run_rem ? 1 : 0);                              \
     STAGE_T st;                                                                                     \
     st.init(a, n_img, x0, tid);                                                                     \
     STAMP(0)                                                                                        \
@@ -391,7 +434,7 @@ __global__ __launch_bounds__(256) void mfma_h3_kernel(const ConvArgs a) {
     __shared__ int4 buf0[SH * SW], buf1[SH * SW];
     const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, n = l & 15, g = l >> 4;
     kernarg_warm<ConvArgs>();
-    const BlockXY bxy = xcd_block();
+    const BlockXY bxy = xcd_block(a.inv_nx);
     const int x0 = bxy.x * MTW, n_img = blockIdx.z;
     const int4 *fr = a.afrag;
     constexpr bool BIASED = mode_biased(MODE);     // requant without v_cvt: sums carry + MAGIC_I (needs |s| < 2^22)
@@ -467,7 +510,8 @@ __global__ __launch_bounds__(256) void mfma_h3_kernel(const ConvArgs a) {
 // 4 waves per SIMD: round 3, same-box A/B at 1080p: 5 waves (96 VGPRs, a handful of spills outside the row loop, a fifth workgroup per
 // CU) ran the last layer 5 % SLOWER than 4 (29.3 vs 27.7 us) and the fused trio 13 % slower (47.1 vs 41.6 us).
 // NV (EPI_LAST only): real accumulator rows per lane group, 3 for up to 12 output channels (last_slot_oc, sesrq_common.h)
-template <int MODE, int EPI, int FAST = 0, int NV = 4>
+// OUTF (EPI_LAST, FAST != 0): the fp32 frame instead of the int8 one (LastStore::store)
+template <int MODE, int EPI, int FAST = 0, int NV = 4, bool OUTF = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void mfma_h5_kernel(const ConvArgs a) {
     constexpr bool GENERAL = mode_general(MODE);
     constexpr int SW = MTW + 8;          // 2 + 64 + 2 halo, + over-read of the kx = 4..7 group
@@ -487,7 +531,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void m
     __shared__ int4 buf0[GENERAL ? CP : SHB * SW], buf1[GENERAL ? CP : SHB * SW];      // general: 4 planes of CP dwords
     const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, n = l & 15, g = l >> 4;
     kernarg_warm<ConvArgs>();
-    const BlockXY bxy = xcd_block();
+    const BlockXY bxy = xcd_block(a.inv_nx);
     const int x0 = bxy.x * MTW, n_img = blockIdx.z;
     using Stage = StageNHWC16<SH, SW, 2, 0, CP, CS>;
     SESRQ_TILE_WALK_BEGIN(MTH, Stage)
@@ -577,7 +621,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void m
                     if constexpr (EPI == EPI_LAST) {
                         // a row below the frame is dropped by its offsets (FAST: the scalar one, else the lanes'), not by a
                         // branch: the four rows stay one basic block
-                        ls.template store<BIASED, FAST, NV>(s4[r], a, y0 + y, zlo, y0 + y < a.H);
+                        ls.template store<BIASED, FAST, NV, OUTF>(s4[r], a, y0 + y, zlo, y0 + y < a.H);
                     }
                 }
                 if constexpr (EPI != EPI_LAST) emit_rows4<EPI, false, BIASED>(s4, a, io, y4, zlo);
@@ -620,8 +664,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void m
                     finish_sums<MODE, NV>(s4[t], acc, ac, a);
                     if constexpr (EPI == EPI_LAST) {
                         // a row below the frame is dropped by its offsets (FAST: the scalar one, else the lanes'), not by a branch
-                        if (j == 0) ls.template store<BIASED, FAST, NV>(s4[t], a, gy, zlo, gy < a.H);
-                        else ls1.template store<BIASED, FAST, NV>(s4[t], a, gy, zlo, gy < a.H);
+                        if (j == 0) ls.template store<BIASED, FAST, NV, OUTF>(s4[t], a, gy, zlo, gy < a.H);
+                        else ls1.template store<BIASED, FAST, NV, OUTF>(s4[t], a, gy, zlo, gy < a.H);
                     }
                 }
                 if constexpr (EPI != EPI_LAST) {
@@ -651,7 +695,7 @@ __global__ __launch_bounds__(256) void mfma_h5p_kernel(const ConvArgs a) {
     __shared__ int4 buf0[SH * SW], buf1[SH * SW];
     const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, n = l & 15, g = l >> 4;
     kernarg_warm<ConvArgs>();
-    const BlockXY bxy = xcd_block();
+    const BlockXY bxy = xcd_block(a.inv_nx);
     const int x0 = bxy.x * MTW, n_img = blockIdx.z;
     const int4 *fr = a.afrag;
     constexpr bool BIASED = mode_biased(MODE);
@@ -860,7 +904,7 @@ __device__ __forceinline__ void mfma_f5_body(const ConvArgs &a, int4 *buf0, int4
     constexpr int SH = F5_SH, SWP = F5_SWP, PITCH = F5_PITCH;
     const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, n = l & 15, g = l >> 4;
     kernarg_warm<ConvArgs>();
-    const BlockXY bxy = xcd_block();
+    const BlockXY bxy = xcd_block(a.inv_nx);
     const int x0 = bxy.x * MTW, n_img = blockIdx.z;
     using Stage = StageFrame<SRC, SH, SWP, PITCH, NCH>;
     static_assert(F5_SH - F5_TH == 4, "StageFrame carries SH - TH = 4 rows");
@@ -1017,6 +1061,9 @@ static void launch(ConvArgs a, hipStream_t st, int tile_h = MTH) {
     long long k = (a.wg_budget > 0 ? (long long)a.wg_budget : (long long)blocks_per_cu * num_cu) / ((long long)strips * a.N);
     k = std::max(1LL, std::min<long long>(k, row_tiles));
     a.chunk_tiles = (int)((row_tiles + k - 1) / k);
+    a.run_q = (int)(row_tiles / k);
+    a.run_rem = (int)(row_tiles % k);
+    a.inv_nx = ((long long)strips * k < 65536 && strips < 65536) ? (unsigned)((0x100000000ULL + (unsigned)strips - 1) / (unsigned)strips) : 0u;
     dim3 grid(strips, (int)k, a.N);
     launch_kernel<KERN>(grid, dim3(256), 0, st, a);
 }
@@ -1108,6 +1155,10 @@ int launch_mfma(const LayerPlan &lp, const ConvArgs &a_in, int src, int epi, boo
             else if (epi == EPI_PRERES) SESRQ_BY_MODE(mfma_h5_kernel, EPI_PRERES);
             // (below) d1: the output requant as one fma -- proven for this layer's (M, n), zero point -128, biased sums, int8 output only
 
+            // fp32 frame only (the reference's return type), no anchor: the OUTF flavours of the same FAST instances
+            else if (!a.out_q && a.out_f && !a.anchor && last_nv(a.oc) == 3 && last_pairmap(a.oc, a.ps)) { if (d1) SESRQ_BY_MODE_B(mfma_h5_kernel, EPI_LAST, 12, 3, true); else if (d2) SESRQ_BY_MODE_B(mfma_h5_kernel, EPI_LAST, 22, 3, true); else SESRQ_BY_MODE(mfma_h5_kernel, EPI_LAST, 2, 3, true); }
+            else if (!a.out_q && a.out_f && !a.anchor && last_nv(a.oc) == 4 && a.ps == 2) { if (d1) SESRQ_BY_MODE_B(mfma_h5_kernel, EPI_LAST, 12, 4, true); else if (d2) SESRQ_BY_MODE_B(mfma_h5_kernel, EPI_LAST, 22, 4, true); else SESRQ_BY_MODE(mfma_h5_kernel, EPI_LAST, 2, 4, true); }
+            else if (!a.out_q && a.out_f && !a.anchor && last_nv(a.oc) == 4 && a.ps == 4) { if (d1) SESRQ_BY_MODE_B(mfma_h5_kernel, EPI_LAST, 14, 4, true); else if (d2) SESRQ_BY_MODE_B(mfma_h5_kernel, EPI_LAST, 24, 4, true); else SESRQ_BY_MODE(mfma_h5_kernel, EPI_LAST, 4, 4, true); }
             else if (last_nv(a.oc) == 3) {       // up to 12 output channels: three real rows per lane group (must match pack_mfma_frags)
                 if (a.out_q && !a.out_f && last_pairmap(a.oc, a.ps)) { if (d1) SESRQ_BY_MODE_B(mfma_h5_kernel, EPI_LAST, 12, 3); else if (d2) SESRQ_BY_MODE_B(mfma_h5_kernel, EPI_LAST, 22, 3); else SESRQ_BY_MODE(mfma_h5_kernel, EPI_LAST, 2, 3); }
                 else SESRQ_BY_MODE(mfma_h5_kernel, EPI_LAST, 0, 3);

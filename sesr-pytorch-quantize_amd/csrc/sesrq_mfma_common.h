@@ -336,12 +336,15 @@ template <typename ARGS>
 __device__ __forceinline__ void kernarg_warm() {
     typedef const int __attribute__((address_space(4))) *karg_t;
     karg_t kp = (karg_t)__builtin_amdgcn_kernarg_segment_ptr();
-    constexpr int LINES = ((int)sizeof(ARGS) + 32 + 63) / 64;      // + the implicit arguments hipcc reads (grid size), which follow the struct
-    static_assert(LINES <= 12, "one asm operand per line");
+    // Only lines of the EXPLICIT argument struct (rounds 3-4 read 32 bytes past it, relying on the implicit arguments hipcc
+    // appends; a build whose code object carries fewer would have read past the segment).  The implicit block counts gridDim reads
+    // follow the struct directly and share its last line or the next one, which the kernel's own first use fetches.
+    constexpr int LINES = ((int)sizeof(ARGS) + 63) / 64;
+    static_assert(LINES <= 12 && sizeof(ARGS) % 4 == 0, "one asm operand per line");
     int t[12];
 #pragma unroll
     for (int i = 0; i < 12; ++i) t[i] = kp[(i < LINES ? i * 16 : 0)];
-    const int last = kp[((int)sizeof(ARGS) + 32) / 4 - 1];
+    const int last = kp[(int)sizeof(ARGS) / 4 - 1];
     asm volatile("" ::"s"(t[0]), "s"(t[1]), "s"(t[2]), "s"(t[3]), "s"(t[4]), "s"(t[5]), "s"(t[6]), "s"(t[7]), "s"(t[8]), "s"(t[9]), "s"(t[10]),
                  "s"(t[11]), "s"(last));
 }
@@ -351,7 +354,9 @@ struct BlockXY { int x, y, t_entry, c_entry; };      // diagnostic build: clocks
 #else
 struct BlockXY { int x, y; };
 #endif
-__device__ __forceinline__ BlockXY xcd_block() {
+// inv_nx = ceil(2^32 / gridDim.x) from the host (0: divide): v / nx == mulhi(v, inv_nx) for v, nx < 2^16 (the error term nx * inv_nx - 2^32 < nx,
+// times v, stays below 2^32) -- the prologue's 32-bit division was ~25 dependent scalar / vector instructions in front of the first load
+__device__ __forceinline__ BlockXY xcd_block(unsigned inv_nx = 0) {
     BlockXY b = {(int)blockIdx.x, (int)blockIdx.y};
 #ifdef SESRQ_STAMPS
     b.t_entry = (int)__builtin_amdgcn_s_memrealtime();
@@ -361,7 +366,7 @@ __device__ __forceinline__ BlockXY xcd_block() {
     const unsigned id = blockIdx.y * nx + blockIdx.x;
     if (id < per * 8) {      // the last total % 8 blocks keep their place
         const unsigned v = (id & 7) * per + (id >> 3);
-        b.y = (int)(v / nx);
+        b.y = inv_nx ? (int)__umulhi(v, inv_nx) : (int)(v / nx);
         b.x = (int)(v - (unsigned)b.y * nx);
     }
     return b;

@@ -123,7 +123,7 @@ __global__ __launch_bounds__(256) void mfma_trio_kernel(const TrioArgs a) {
     const float lut_magic = MAGIC + 256.f + (float)(unsigned)(size_t)(const __attribute__((address_space(3))) void *)lutp;
     const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, n = l & 15, g = l >> 4;
     kernarg_warm<TrioArgs>();
-    const BlockXY bxy = xcd_block();
+    const BlockXY bxy = xcd_block(a.inv_nx);
     const int n_img = blockIdx.z;
     const int x0 = bxy.x * TV - 2;              // frame column of computed column 0
     // vertical runs of (almost) equal length: run c of n covers units [c*U/n, (c+1)*U/n) of a.run_unit rows -- whole steps (8), or
@@ -131,9 +131,9 @@ __global__ __launch_bounds__(256) void mfma_trio_kernel(const TrioArgs a) {
     // one closing half step.  A 540p frame on a full chip has 1 - 2 steps per run: 8- and 16-row runs became 8- and 12-row
     // runs, 18.8 -> 14.8 us.  Long runs (1080p: 4 - 5 steps) gain nothing from it -- the workgroups that finish early leave
     // their issue slots to the others -- and a half step costs more than half a step, so they stay on whole steps.
-    const int units_total = (a.H + a.run_unit - 1) / a.run_unit;
-    const int y_begin = a.run_unit * (int)(((long long)bxy.y * units_total) / gridDim.y);
-    const int y_end = a.run_unit * (int)(((long long)(bxy.y + 1) * units_total) / gridDim.y);
+    const int u_begin = bxy.y * a.run_q + min(bxy.y, a.run_rem);      // the host divided (launch_trio_k): no division in the prologue
+    const int y_begin = a.run_unit * u_begin;
+    const int y_end = a.run_unit * (u_begin + a.run_q + (bxy.y < a.run_rem ? 1 : 0));
     if (y_begin >= y_end) return;
     // The frame loads of the cold-start window are the FIRST vector-memory requests of the wave; the table and the A fragments follow and
     // arrive beside them (memory returns loads in order): the prologue used to wait for the table's round trip (global load -> LDS write)
@@ -370,6 +370,10 @@ static void launch_trio_k(TrioArgs a, hipStream_t st) {
     k = std::max(1LL, std::min<long long>(k, steps));                     // a run is at least one full step on average
     a.chunk_steps = (int)((steps + k - 1) / k);
     a.run_unit = (steps < 3 * k) ? TH / 2 : TH;                           // short runs (< 3 steps) are cut in half-step units
+    const int units_total = (a.H + a.run_unit - 1) / a.run_unit;
+    a.run_q = (int)(units_total / k);
+    a.run_rem = (int)(units_total % k);
+    a.inv_nx = ((long long)strips * k < 65536 && strips < 65536) ? (unsigned)((0x100000000ULL + (unsigned)strips - 1) / (unsigned)strips) : 0u;
     dim3 grid(strips, (int)k, a.N);
     launch_kernel<KERN>(grid, dim3(256), (unsigned)lds, st, a);
 }

@@ -40,12 +40,16 @@ def test_no_valu_write_behind_a_wide_store(stem, tmp_path):
                 continue
             mm = re.match(r"s_load_dword s\d+, s\[0:1\], (0x[0-9a-f]+|\d+)$", t)
             if not mm:
+                if re.match(r"s_load_dwordx\d+ s\[\d+:\d+\], s\[0:1\], ", t):
+                    continue                              # an argument load of the kernel proper, scheduled into the batch
                 break
             warm.append(int(mm.group(1), 0))
         if warm:
             kernels += 1
             warm.sort()                                   # the scheduler may permute the batch
             assert len(warm) >= 4 and warm[0] == 0 and max(warm) + 4 <= size, (m.group(1), warm, size)
+            # ... and inside the EXPLICIT argument struct: the implicit arguments begin 256 bytes before the end of the segment
+            assert max(warm) + 4 <= size - 256 + 4, (m.group(1), warm, size)
             assert all(b - a <= 64 for a, b in zip(warm, warm[1:])), (m.group(1), warm)     # no line of the segment skipped
     assert kernels >= 5, kernels
 

@@ -7,13 +7,14 @@ NAME=$1; EXTRA=$2; shift 2
 SRC=$ROOT/sesr-pytorch-quantize_amd/csrc; LIB=$ROOT/sesr-pytorch-quantize_amd/lib; OUT=$LIB/$NAME
 FILES=${@:-sesrq_mfma sesrq_trio}
 mkdir -p $OUT
-FLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -fno-fast-math -mllvm -amdgpu-mfma-vgpr-form -I$ROOT/include -Wall -Wno-unused-result"
+FLAGS=$(make -s -C $SRC print-cxxflags)      # the library's own flags (a hand copy drifts)
 pids=()
 for f in $FILES; do /opt/rocm/bin/hipcc $FLAGS $(make -s -C $SRC print-fileflags-$f) $EXTRA -c $SRC/$f.hip -o $OUT/$f.o & pids+=($!); done      # the library's per-file flags first: EXTRA can override them
 for p in "${pids[@]}"; do wait $p; done
 OBJS=""
-for f in sesrq_api sesrq_dot4 sesrq_mfma sesrq_trio sesrq_quad sesrq_verify sesrq_calib; do
-  if [ -f $SRC/$f.hip ]; then if [ -f $OUT/$f.o ]; then OBJS="$OBJS $OUT/$f.o"; else OBJS="$OBJS $LIB/$f.o"; fi; fi
+for s in $(make -s -C $SRC print-srcs); do
+  f=${s%.hip}
+  if [ -f $OUT/$f.o ]; then OBJS="$OBJS $OUT/$f.o"; else OBJS="$OBJS $LIB/$f.o"; fi
 done
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $OUT/libsesrq.so $OBJS
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -Wl,-soname,libsesrq.so -o $OUT/libsesrq.so $OBJS
 echo "built $OUT/libsesrq.so"

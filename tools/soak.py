@@ -14,7 +14,7 @@ rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 dev = torch.device("cuda:0")
 # SOAK_BUNDLE / SOAK_SHAPE / SOAK_GROUP: another net, frame size, frames per launch sequence (e.g. nrdm_3.crop.npz 3x540x960 8)
 b = Bundle.load(os.path.join(ROOT, "tests/golden", os.environ.get("SOAK_BUNDLE", "sesr_x2_rand.crop.npz")))
-e = sesrq.Engine(b, dev, engine=_lib.ENGINE_MFMA, wg_budget=512)
+e = sesrq.Engine(b, dev, engine=_lib.ENGINE_MFMA, wg_budget=2 * torch.cuda.get_device_properties(dev).multi_processor_count)      # two slots per CU, as bench.py scales its plan
 S, F, G = 3, 24, int(os.environ.get("SOAK_GROUP", "1"))
 shape = tuple(int(v) for v in os.environ.get("SOAK_SHAPE", "3x1080x1920").split("x"))
 g = torch.Generator(device="cpu").manual_seed(7)
