@@ -88,6 +88,13 @@ typedef struct sesrq_layer_desc {
     uint32_t M;                /* < 2^16  (define.py REQUAN_BIT)   */
     uint32_t n;                /* <= 32   (define.py REQUAN_N_MAX) */
     int32_t relu;
+    /* Per-OUTPUT-CHANNEL requant constants [oc], or both NULL (the reference: one (M, n) per layer).  No reference counterpart -- its
+     * weight quantiser is per tensor (myQL/quan_func.py:58-71); BASELINE's north star names per-channel weight scales: with a weight scale
+     * per output channel the layer's requant multiplier s_in / s_next * s_w[oc] becomes per channel, t = f32(f32(acc) * f32(M_oc[oc])) *
+     * 2^-n_oc[oc], and add_const[oc] is formed with s_w[oc].  PARITY UNPINNED (oracle <-> HIP self-consistency only).  A layer with these
+     * set runs on the dot4 kernels (round 5; the MFMA kernels keep the per-tensor form and pay nothing for the option); M and n are ignored. */
+    const uint32_t *M_oc;
+    const uint32_t *n_oc;
 } sesrq_layer_desc;
 
 /* A whole net ("parameter bundle"; replaces the CWD-relative output_pt/ tree).
@@ -276,6 +283,9 @@ int sesrq_calib_fakequant(const float *in, float *out, size_t n, float scale, in
 int sesrq_requant_const(double r, int data_bit, int shift_max, uint32_t *M, uint32_t *n);
 /* quantize_symmetrical_by_tensor (myQL/quan_func.py:58-71): per-tensor symmetric INT8. */
 int sesrq_quantize_weight(const float *w, size_t count, int width, int8_t *wq, double *scale);
+/* The same per OUTPUT CHANNEL (w: [oc][per_oc]): scale_oc[o] = 2 * absmax(w[o]) / (2^width - 1), wq = clamp(rint(w / f32(scale_oc[o]))).  No
+ * reference counterpart (see sesrq_layer_desc.M_oc); an all-zero channel is an error like the reference's all-zero tensor. */
+int sesrq_quantize_weight_per_channel(const float *w, int oc, size_t per_oc, int width, int8_t *wq, double *scale_oc);
 /* quantize_bias_with_scale + add-constant (myQL/quan_func.py:402,448-449,481-486). */
 int sesrq_add_const(const float *bias, const int8_t *wq, int oc, int per_oc, double s_in, int z_in,
                     double s_w, int bias_width, int32_t *out);

@@ -37,6 +37,8 @@ def forward(net, x, threads=0, keep=False, want_f=True):
     keepalive = []
     layers = (_Layer * L)()
     for k, l in enumerate(net.layers):
+        if getattr(l, "M_oc", None) is not None:
+            raise NotImplementedError("the C oracle restates the reference's per-tensor requant only; per-channel nets (unpinned) use the numpy oracle")
         w = np.ascontiguousarray(l.wq, np.int8)
         a = np.ascontiguousarray(l.add_const, np.int32)
         keepalive += [w, a]

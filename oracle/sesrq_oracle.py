@@ -92,6 +92,11 @@ class Layer:
     M: int
     n: int
     relu: bool
+    # Per-OUTPUT-CHANNEL requant constants, or None = the reference's one (M, n) per layer.  NOT in the reference (its weight quantiser is per
+    # tensor, quan_func.py:58-71); BASELINE's north star names per-channel weight scales.  PARITY UNPINNED: this is the definition the HIP
+    # path is checked against, nothing of the reference pins it.  t[oc] = f32(f32(acc[oc]) * f32(M_oc[oc])) * 2^-n_oc[oc].
+    M_oc: Optional[np.ndarray] = None
+    n_oc: Optional[np.ndarray] = None
 
 
 @dataclass
@@ -112,8 +117,15 @@ class Net:
         return len(self.layers)
 
 
+def quantize_weight_per_channel(w: np.ndarray, width: int = 8):
+    """One symmetric scale per OUTPUT channel (no reference counterpart; parity unpinned): quantize_weight applied to every w[oc]."""
+    w = np.asarray(w, dtype=F32)
+    qs = [quantize_weight(w[o], width) for o in range(w.shape[0])]
+    return np.stack([q for q, _ in qs]), np.array([s for _, s in qs], dtype=np.float64)
+
+
 def derive_net(Wf: List[np.ndarray], bf: List[np.ndarray], scale: List[float], zero: List[int],
-               pixel_shuffle: int, name: str = "") -> Net:
+               pixel_shuffle: int, name: str = "", per_channel: bool = False) -> Net:
     """float collapsed convs + calibrated (scale, zero) -> integer parameter bundle.
 
     Role rules restate myQL/quan_func.py:523-609: layer 0 and layer L-2 requantise into
@@ -125,8 +137,15 @@ def derive_net(Wf: List[np.ndarray], bf: List[np.ndarray], scale: List[float], z
     L = len(Wf)
     layers = []
     for k in range(L):
-        wq, sw = quantize_weight(Wf[k])
         nxt = 1 if k in (0, L - 2) else k + 1
+        if per_channel:      # unpinned variant: the layer's requant multiplier and bias constant per output channel
+            wq, sws = quantize_weight_per_channel(Wf[k])
+            Mn = [qconst(scale[k] / scale[nxt] * float(s_)) for s_ in sws]
+            ac = np.concatenate([add_const(np.asarray(bf[k])[o:o + 1], wq[o:o + 1], scale[k], zero[k], float(sws[o])) for o in range(wq.shape[0])])
+            layers.append(Layer(wq=wq, add_const=ac, M=Mn[0][0], n=Mn[0][1], relu=(k != L - 1),
+                                M_oc=np.array([m for m, _ in Mn], np.int64), n_oc=np.array([n_ for _, n_ in Mn], np.int64)))
+            continue
+        wq, sw = quantize_weight(Wf[k])
         M, n = qconst(scale[k] / scale[nxt] * sw)
         layers.append(Layer(wq=wq, add_const=add_const(bf[k], wq, scale[k], zero[k], sw), M=M, n=n, relu=(k != L - 1)))
     M_res, n_res = qconst(scale[1] / scale[L - 1])
@@ -193,10 +212,15 @@ def conv_pe(q: np.ndarray, lay: Layer, z_in: int, pe: int, acc_bits: int, add_bi
     return pe_out, acc
 
 
-def requant(acc: np.ndarray, M: int, n: int) -> np.ndarray:
+def requant(acc: np.ndarray, M, n) -> np.ndarray:
     """t = f32(f32(acc) * f32(M)) * 2**-n   -- myQL/quan_func.py:529,560,584,605.
 
-    The fp32 rounding of the product is load-bearing (|acc*M| reaches 2**31..2**32)."""
+    The fp32 rounding of the product is load-bearing (|acc*M| reaches 2**31..2**32).  M, n: the layer's scalars, or [OC] arrays for the
+    unpinned per-output-channel variant (Layer.M_oc): the same two fp32 operations with the channel's own constants."""
+    if np.ndim(M):
+        Mv = np.asarray(M, dtype=np.float64).astype(F32)[None, :, None, None]
+        sh = np.exp2(-np.asarray(n, dtype=np.float64)).astype(F32)[None, :, None, None]
+        return (acc.astype(F32) * Mv) * sh
     return (acc.astype(F32) * F32(M)) * F32(2.0 ** (-n))
 
 
@@ -230,7 +254,7 @@ def forward(net: Net, x: np.ndarray, keep: bool = False) -> Dict[str, np.ndarray
             st[f"pe_raw{k}"] = pe_raw                  # all frames, int64, un-saturated
             st[f"pe_out{k}"] = pe_out[0].astype(np.int32)
             st[f"pe_add{k}"] = (acc - lay.add_const.astype(np.int64)[None, :, None, None]).astype(np.int32)
-        t = requant(acc, lay.M, lay.n)
+        t = requant(acc, lay.M, lay.n) if lay.M_oc is None else requant(acc, lay.M_oc, lay.n_oc)
         if lay.relu:
             t = np.maximum(t, F32(0))
         if k == L - 1:

@@ -189,6 +189,7 @@ struct ConvArgs {
     int relu;
     int ps;                  // EPI_LAST pixel shuffle factor
     int add_const[SESRQ_MAX_CH];
+    const float2 *mn_oc;     // dot4 kernels: per-output-channel ((float)M, 2^-n) [oc] of a per-channel layer (sesrq_layer_desc.M_oc), or NULL
     FrameTable ft;           // MFMA first / last layer kernels only (ft.n == 0: one contiguous batch at in / out_q / out_f)
 };
 
@@ -230,6 +231,7 @@ struct LayerPlan {
     int4 *d_afrag_pesplit = nullptr; // device: last layer with OC <= 4 (MFMA_H5P image), else NULL
     int4 *d_afrag_sparse = nullptr;  // device: first layer, exactly one risky PE, 3 input channels: sparse hybrid images, else NULL
     int4 *d_afrag_others = nullptr;  // device: exactly one risky PE: merged image with that PE's channels zeroed, else NULL
+    float2 *d_mn_oc = nullptr;       // device: per-output-channel ((float)M, 2^-n), per-channel layers only (they run on the dot4 kernels)
     std::string engine_dot4, engine_mfma;
     ConvArgs base;           // constant fields prefilled
     // static saturation analysis (per layer)

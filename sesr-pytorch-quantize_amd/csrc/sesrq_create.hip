@@ -203,6 +203,9 @@ int sesrq_create(const sesrq_net_desc *d, const sesrq_options *opts, sesrq_net *
         if (l.ic < 1 || l.ic > SESRQ_MAX_CH || l.oc < 1 || l.oc > SESRQ_MAX_CH) { set_error("sesrq_create: channels must be 1..16"); return 1; }
         if (!l.w || !l.add_const) { set_error("sesrq_create: null weight/add_const"); return 1; }
         if (l.M >= (1u << 16) || l.n > 32) { set_error("sesrq_create: requant constant out of range (M < 2^16, n <= 32)"); return 1; }
+        if ((l.M_oc != nullptr) != (l.n_oc != nullptr)) { set_error("sesrq_create: per-channel requant constants need both M_oc and n_oc"); return 1; }
+        for (int o = 0; l.M_oc && o < l.oc && o < SESRQ_MAX_CH; ++o)
+            if (l.M_oc[o] >= (1u << 16) || l.n_oc[o] > 32) { set_error("sesrq_create: per-channel requant constant out of range (M < 2^16, n <= 32)"); return 1; }
         if (k > 0 && l.ic != d->layers[k - 1].oc) { set_error("sesrq_create: channel mismatch between consecutive layers"); return 1; }
         if (k < L - 1 && k > 0 && l.oc != 16 && l.oc > 16) { set_error("sesrq_create: hidden width > 16"); return 1; }
         for (int o = 0; o < l.oc; ++o)
@@ -266,7 +269,16 @@ int sesrq_create(const sesrq_net_desc *d, const sesrq_options *opts, sesrq_net *
             return 1;
         }
         lp.mfma_kind = MFMA_NONE;
-        if (k == 0) { if (l.k == 5 && l.ic <= 4) lp.mfma_kind = MFMA_F5; }
+        if (l.M_oc) {      // per-output-channel requant constants: a device table for the dot4 kernels; no MFMA kernel, no trio, no grouping
+            float2 mn[SESRQ_MAX_CH];
+            for (int o = 0; o < SESRQ_MAX_CH; ++o) mn[o] = o < l.oc ? make_float2((float)l.M_oc[o], ldexpf(1.0f, -(int)l.n_oc[o])) : make_float2(0.f, 0.f);
+            if (hipMalloc((void **)&lp.d_mn_oc, sizeof(mn)) != hipSuccess || hipMemcpy(lp.d_mn_oc, mn, sizeof(mn), hipMemcpyHostToDevice) != hipSuccess) {
+                set_error("sesrq_create: device upload failed");
+                sesrq_destroy(net);
+                return 1;
+            }
+        }
+        else if (k == 0) { if (l.k == 5 && l.ic <= 4) lp.mfma_kind = MFMA_F5; }
         else if (l.k == 3 && k < L - 1) lp.mfma_kind = MFMA_H3;
         else if (l.k == 5) lp.mfma_kind = MFMA_H5;
         if (lp.mfma_kind != MFMA_NONE) {
@@ -342,13 +354,15 @@ int sesrq_create(const sesrq_net_desc *d, const sesrq_options *opts, sesrq_net *
             }
             a.Cs = a.Cd - 128.f;
         }
+        if (l.M_oc) a.direct = 0;
+        a.mn_oc = lp.d_mn_oc;
         a.Mres = (float)d->M_res; a.shres = ldexpf(1.0f, -(int)d->n_res);
         a.z_merge = (float)d->zero[L - 1];
         a.s_in = d->scale_in; a.z_in = (float)d->zero[0];
         a.s_out = d->scale_out; a.z_out = (float)d->zero[L];
         a.ps = d->pixel_shuffle;
         for (int o = 0; o < l.oc; ++o) a.add_const[o] = l.add_const[o];
-        lp.engine_dot4 = lp.general ? "dot4-general" : "dot4-merged";
+        lp.engine_dot4 = std::string(lp.general ? "dot4-general" : "dot4-merged") + (l.M_oc ? "-perchannel" : "");
         static const char *kn[] = {"", "mfma-h3", "mfma-h5", "mfma-f5"};
         const bool hyb = lp.general && __builtin_popcount(lp.risky_mask) == 1 && d->pe_acc_bits == 18 && d->pe_add_bits == 20;
         lp.engine_mfma = lp.mfma_kind == MFMA_NONE ? lp.engine_dot4 : std::string(kn[lp.mfma_kind]) + (hyb ? "-hybrid" : (lp.general ? "-general" : "-merged"));
@@ -408,6 +422,7 @@ void sesrq_destroy(sesrq_net *net) {
         if (lp.d_afrag_pesplit) (void)hipFree(lp.d_afrag_pesplit);
         if (lp.d_afrag_others) (void)hipFree(lp.d_afrag_others);
         if (lp.d_afrag_sparse) (void)hipFree(lp.d_afrag_sparse);
+        if (lp.d_mn_oc) (void)hipFree(lp.d_mn_oc);
     }
     delete net;
 }

@@ -151,7 +151,9 @@ __global__ __launch_bounds__(256) void conv_dot4_kernel(const ConvArgs a) {
             s = acc[0][o];
         }
         s += a.add_const[o];
-        float v = __fmul_rn((float)s, a.Mf) * a.sh;
+        // per-output-channel requant constants (sesrq_layer_desc.M_oc; wave-uniform: scalar loads) or the layer's one (M, n)
+        const float Mf_o = a.mn_oc ? a.mn_oc[o < SESRQ_MAX_CH ? o : 0].x : a.Mf, sh_o = a.mn_oc ? a.mn_oc[o < SESRQ_MAX_CH ? o : 0].y : a.sh;
+        float v = __fmul_rn((float)s, Mf_o) * sh_o;
         if (a.relu) v = fmaxf(v, 0.f);
         t[o] = v;
         if (a.dbg_t && o < a.oc) a.dbg_t[((size_t)n * a.oc + o) * HW + (size_t)gy * W + gx] = v;      // layer 0: shortcut_tensor.pt (quan_func.py:529-549)

@@ -58,6 +58,16 @@ int sesrq_quantize_weight(const float *w, size_t count, int width, int8_t *wq, d
     return 0;
 }
 
+int sesrq_quantize_weight_per_channel(const float *w, int oc, size_t per_oc, int width, int8_t *wq, double *scale_oc) {
+    if (!w || !wq || !scale_oc || oc < 1 || per_oc == 0) { set_error("sesrq_quantize_weight_per_channel: null/empty argument"); return 1; }
+    for (int o = 0; o < oc; ++o)
+        if (sesrq_quantize_weight(w + (size_t)o * per_oc, per_oc, width, wq + (size_t)o * per_oc, scale_oc + o)) {
+            set_error("sesrq_quantize_weight_per_channel: output channel " + std::to_string(o) + ": " + sesrq_last_error());
+            return 1;
+        }
+    return 0;
+}
+
 int sesrq_add_const(const float *bias, const int8_t *wq, int oc, int per_oc, double s_in, int z_in, double s_w, int bias_width,
                     int32_t *out) {
     if (!bias || !wq || !out || oc < 1 || per_oc < 1) { set_error("sesrq_add_const: bad argument"); return 1; }

@@ -36,6 +36,11 @@ OUTPUT_PE_W_FLG = w_flg_c and True
 OUTPUT_PE_ADD_W_FLG = w_flg_c and True
 REQUAN_FACTOR_W_FLG = w_flg_c and True
 
+# NOT in the reference's define.py: one weight scale per OUTPUT channel instead of the reference's one per tensor (myQL/quan_func.py:58-71).
+# BASELINE's north star names per-channel weights; nothing of the reference pins them (parity unpinned) and such layers run on the dot4
+# kernels.  Read by quantize_model_weight at call time; the default is the reference's behaviour.
+WEIGHT_PER_CHANNEL = False
+
 WEIGHT_W_HIST_PNG = False
 INPUT_W_HIST_PNG = False
 

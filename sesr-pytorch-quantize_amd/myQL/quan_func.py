@@ -53,6 +53,15 @@ def quantize_symmetrical_by_tensor(tensor_input: torch.Tensor, width: int, exe_m
     """exe mode 0: fake-quantised float weights; exe mode 1: integer-valued weights."""
     w = tensor_input.detach().cpu().numpy().astype(np.float32)
     assert float(np.abs(w).max()) > 0, "Conv2d weight tensor is all zero"
+    import define
+    if getattr(define, "WEIGHT_PER_CHANNEL", False):
+        # this package's extension (define.WEIGHT_PER_CHANNEL; the reference is per tensor): one scale per output channel, stored as an [OC]
+        # tensor under the same key -- the lowering then derives per-channel requant constants (sesrq_layer_desc.M_oc)
+        wq, scales = sesrq.quantize_weight_per_channel(w, width)
+        STORE[f"weight/conv.weight.{func_id}.scale"] = torch.from_numpy(scales)
+        STORE[f"weight/conv.weight.{func_id}"] = torch.from_numpy(wq.astype(np.float32))
+        q = torch.from_numpy(wq.astype(np.float32)).to(tensor_input.device)
+        return q * torch.from_numpy(scales.astype(np.float32)).to(q.device).reshape(-1, 1, 1, 1) if exe_mode == 0 else q
     wq, scale = sesrq.quantize_weight(w, width)
     STORE[f"weight/conv.weight.{func_id}.scale"] = scale
     STORE[f"weight/conv.weight.{func_id}"] = torch.from_numpy(wq.astype(np.float32))

@@ -1,8 +1,8 @@
 """sesrq -- MI355X-native INT8 SESR / NRDM integer inference (host side of libsesrq.so)."""
 from . import _lib
-from .bundle import Bundle, LayerParams, derive_bundle, requant_const, requant_form, quantize_weight, add_const, calib_scale_zero
+from .bundle import Bundle, LayerParams, derive_bundle, requant_const, requant_form, quantize_weight, quantize_weight_per_channel, add_const, calib_scale_zero
 
-__all__ = ["Bundle", "LayerParams", "derive_bundle", "requant_const", "requant_form", "quantize_weight", "add_const",
+__all__ = ["Bundle", "LayerParams", "derive_bundle", "requant_const", "requant_form", "quantize_weight", "quantize_weight_per_channel", "add_const",
            "calib_scale_zero", "Engine"]
 
 

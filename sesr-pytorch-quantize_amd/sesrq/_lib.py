@@ -22,7 +22,8 @@ ABI_VERSION = 4
 class LayerDesc(C.Structure):
     _fields_ = [("k", C.c_int32), ("ic", C.c_int32), ("oc", C.c_int32),
                 ("w", C.POINTER(C.c_int8)), ("add_const", C.POINTER(C.c_int32)),
-                ("M", C.c_uint32), ("n", C.c_uint32), ("relu", C.c_int32)]
+                ("M", C.c_uint32), ("n", C.c_uint32), ("relu", C.c_int32),
+                ("M_oc", C.POINTER(C.c_uint32)), ("n_oc", C.POINTER(C.c_uint32))]
 
 
 class NetDesc(C.Structure):
@@ -86,6 +87,8 @@ SYMBOLS = {
     "sesrq_requant_const": (C.c_int, [C.c_double, C.c_int, C.c_int, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     "sesrq_quantize_weight": (C.c_int, [C.POINTER(C.c_float), C.c_size_t, C.c_int, C.POINTER(C.c_int8),
                                         C.POINTER(C.c_double)]),
+    "sesrq_quantize_weight_per_channel": (C.c_int, [C.POINTER(C.c_float), C.c_int, C.c_size_t, C.c_int, C.POINTER(C.c_int8),
+                                                    C.POINTER(C.c_double)]),
     "sesrq_add_const": (C.c_int, [C.POINTER(C.c_float), C.POINTER(C.c_int8), C.c_int, C.c_int, C.c_double, C.c_int,
                                   C.c_double, C.c_int, C.POINTER(C.c_int32)]),
     "sesrq_calib_scale_zero": (C.c_int, [C.c_double, C.c_double, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int)]),

@@ -7,7 +7,7 @@ from __future__ import annotations
 import ctypes as C
 import json
 from dataclasses import dataclass, field
-from typing import List, Sequence
+from typing import List, Optional, Sequence
 
 import numpy as np
 
@@ -22,6 +22,10 @@ class LayerParams:
     n: int                  # n_K_K+1.pt
     relu: bool = True
     w_scale: float = 0.0    # conv.weight.K.scale.pt (informational once M/n are derived)
+    # per-OUTPUT-CHANNEL requant constants (sesrq_layer_desc.M_oc / n_oc) or None = the reference's per-tensor (M, n).  No reference counterpart
+    # (its weight quantiser is per tensor): parity unpinned; such a layer runs on the dot4 kernels
+    M_oc: Optional[np.ndarray] = None
+    n_oc: Optional[np.ndarray] = None
 
 
 @dataclass
@@ -57,6 +61,9 @@ class Bundle:
                     pe_acc_bits=self.pe_acc_bits, pe_add_bits=self.pe_add_bits, name=self.name)
         arrs = {f"Wq{k}": l.wq for k, l in enumerate(self.layers)}
         arrs.update({f"add_const{k}": l.add_const for k, l in enumerate(self.layers)})
+        for k, l in enumerate(self.layers):
+            if l.M_oc is not None:
+                arrs[f"M_oc{k}"], arrs[f"n_oc{k}"] = np.asarray(l.M_oc, np.uint32), np.asarray(l.n_oc, np.uint32)
         np.savez_compressed(path, meta=np.array(json.dumps(meta)), **arrs)
 
     @staticmethod
@@ -70,7 +77,9 @@ class Bundle:
         if ps is None:                       # golden fixtures carry the reference's MFLAG instead
             ps = {5: 4, 6: 2, 3: 1}[m["mflag"]]
         layers = [LayerParams(wq=z[f"Wq{k}"].astype(np.int8), add_const=z[f"add_const{k}"].astype(np.int32),
-                              M=int(m["M"][k]), n=int(m["n"][k]), relu=bool(relu[k]), w_scale=float(wsc[k]))
+                              M=int(m["M"][k]), n=int(m["n"][k]), relu=bool(relu[k]), w_scale=float(wsc[k]),
+                              M_oc=z[f"M_oc{k}"].astype(np.uint32) if f"M_oc{k}" in z.files else None,
+                              n_oc=z[f"n_oc{k}"].astype(np.uint32) if f"n_oc{k}" in z.files else None)
                   for k in range(L)]
         return Bundle(layers=layers, scale=[float(s) for s in m["scale"]], zero=[int(v) for v in m["zero"]],
                       M_res=int(m["M_res"]), n_res=int(m["n_res"]), pixel_shuffle=int(ps),
@@ -101,6 +110,18 @@ def quantize_weight(w: np.ndarray, width: int = 8):
     return q, float(s.value)
 
 
+def quantize_weight_per_channel(w: np.ndarray, width: int = 8):
+    """(OC, ...) float weights -> (int8 weights, [OC] scales), one symmetric scale per OUTPUT channel (sesrq_quantize_weight_per_channel;
+    no reference counterpart: its quantiser is per tensor, quan_func.py:58-71)."""
+    w = np.ascontiguousarray(w, dtype=np.float32)
+    q = np.empty(w.shape, np.int8)
+    oc = w.shape[0]
+    s = (C.c_double * oc)()
+    _lib.check(_lib.lib().sesrq_quantize_weight_per_channel(w.ctypes.data_as(C.POINTER(C.c_float)), oc, w.size // oc, width,
+                                                            q.ctypes.data_as(C.POINTER(C.c_int8)), s), ValueError)
+    return q, np.array(list(s), dtype=np.float64)
+
+
 def add_const(bias: np.ndarray, wq: np.ndarray, s_in: float, z_in: int, s_w: float, bias_width: int = 16):
     bias = np.ascontiguousarray(bias, dtype=np.float32)
     wq = np.ascontiguousarray(wq, dtype=np.int8)
@@ -121,12 +142,13 @@ def calib_scale_zero(min_val: float, max_val: float, width: int = 8):
 def derive_bundle(weights: Sequence[np.ndarray], biases: Sequence[np.ndarray], scale: Sequence[float],
                   zero: Sequence[int], pixel_shuffle: int, name: str = "", quan_bit: int = 8, bias_bit: int = 16,
                   requan_bit: int = 16, requan_n_max: int = 32, pe_num: int = 4, pe_acc_bits: int = 18,
-                  pe_add_bits: int = 20) -> Bundle:
+                  pe_add_bits: int = 20, per_channel: bool = False) -> Bundle:
     """Float collapsed convs + calibrated (scale, zero) -> integer bundle.
+    per_channel: one weight scale per OUTPUT channel instead of the reference's one per tensor (parity unpinned).
 
     Layer roles by position, as in myQL/quan_func.py:523-609: layers 0 and L-2 requantise into
     domain 1, layer L-1 into domain L, the rest into k+1; residual multiplier s_1/s_{L-1}."""
-    quantised = [quantize_weight(w, quan_bit) for w in weights]
+    quantised = [(quantize_weight_per_channel if per_channel else quantize_weight)(w, quan_bit) for w in weights]
     return derive_bundle_from_quantized([q for q, _ in quantised], [s for _, s in quantised], biases, scale, zero,
                                         pixel_shuffle, name=name, bias_bit=bias_bit, requan_bit=requan_bit,
                                         requan_n_max=requan_n_max, pe_num=pe_num, pe_acc_bits=pe_acc_bits,
@@ -143,8 +165,17 @@ def derive_bundle_from_quantized(wqs: Sequence[np.ndarray], w_scales: Sequence[f
         raise ValueError("derive_bundle: need L+1 scales and zeros")
     layers = []
     for k in range(L):
-        wq, sw = np.ascontiguousarray(wqs[k], dtype=np.int8), float(w_scales[k])
+        wq = np.ascontiguousarray(wqs[k], dtype=np.int8)
         nxt = 1 if k in (0, L - 2) else k + 1
+        if np.ndim(w_scales[k]) == 1:      # one weight scale per output channel (no reference counterpart): per-channel requant constants
+            sws = np.asarray(w_scales[k], np.float64)
+            Mn = [requant_const(scale[k] / scale[nxt] * float(s), requan_bit, requan_n_max) for s in sws]
+            ac = np.concatenate([add_const(np.asarray(biases[k], np.float32)[o:o + 1], wq[o:o + 1], scale[k], zero[k], float(sws[o]), bias_bit)
+                                 for o in range(wq.shape[0])])
+            layers.append(LayerParams(wq=wq, add_const=ac, M=Mn[0][0], n=Mn[0][1], relu=(k != L - 1), w_scale=float(sws.max()),
+                                      M_oc=np.array([m for m, _ in Mn], np.uint32), n_oc=np.array([n for _, n in Mn], np.uint32)))
+            continue
+        sw = float(w_scales[k])
         M, n = requant_const(scale[k] / scale[nxt] * sw, requan_bit, requan_n_max)
         layers.append(LayerParams(wq=wq, add_const=add_const(biases[k], wq, scale[k], zero[k], sw, bias_bit),
                                   M=M, n=n, relu=(k != L - 1), w_scale=sw))

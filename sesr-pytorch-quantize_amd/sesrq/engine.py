@@ -155,6 +155,14 @@ class Engine:
                                        w=w.ctypes.data_as(C.POINTER(C.c_int8)),
                                        add_const=ac.ctypes.data_as(C.POINTER(C.c_int32)),
                                        M=l.M, n=l.n, relu=int(l.relu))
+            if getattr(l, "M_oc", None) is not None:      # per-output-channel requant constants (that layer runs on the dot4 kernels)
+                moc = np.ascontiguousarray(l.M_oc, dtype=np.uint32)
+                noc = np.ascontiguousarray(l.n_oc, dtype=np.uint32)
+                if moc.shape != (w.shape[0],) or noc.shape != (w.shape[0],):
+                    raise ValueError("per-channel requant constants: one (M, n) per output channel")
+                self._keep += [moc, noc]
+                layers[k].M_oc = moc.ctypes.data_as(C.POINTER(C.c_uint32))
+                layers[k].n_oc = noc.ctypes.data_as(C.POINTER(C.c_uint32))
         zero = (C.c_int32 * (L + 1))(*bundle.zero)
         desc = _lib.NetDesc(n_layers=L, layers=layers, zero=zero,
                             scale_in=float(np.float32(bundle.scale[0])), scale_out=float(np.float32(bundle.scale[L])),

@@ -94,7 +94,9 @@ def lower(gm: torch.fx.GraphModule, store=STORE) -> Bundle:
             raise RuntimeError(f"sesrq lowering: conv {k} weights are not INT8-valued; run "
                                "quantize_model_weight(model, 8, 1) before splicing (sim.py:85)")
         wq.append(wt.astype(np.int8))
-        wsc.append(float(store[f"weight/conv.weight.{k}.scale"]))
+        sc_k = store[f"weight/conv.weight.{k}.scale"]
+        # a scalar (the reference) or, with define.WEIGHT_PER_CHANNEL, an [OC] tensor: per-channel requant constants for this layer
+        wsc.append(np.asarray(sc_k, dtype=np.float64).reshape(-1) if hasattr(sc_k, "shape") and len(getattr(sc_k, "shape", ())) == 1 else float(sc_k))
         biases.append(np.asarray(pb.kwargs["bias"], dtype=np.float32))
     ps = 1
     users = list(prev_tail.users)
@@ -140,7 +142,11 @@ def lower_calibration(gm: torch.fx.GraphModule, device, store=STORE):
         widths = (int(pb.kwargs["pe_add_width"]), int(pb.kwargs["pe_acc_width"]), int(pb.kwargs["bias_width"]))
         wq = np.asarray(store[f"weight/conv.weight.{k}"].cpu().numpy() if hasattr(store[f"weight/conv.weight.{k}"], "cpu")
                         else store[f"weight/conv.weight.{k}"])
-        quantized.append((wq.astype(np.int8), float(store[f"weight/conv.weight.{k}.scale"])))
+        sc_k = store[f"weight/conv.weight.{k}.scale"]
+        if hasattr(sc_k, "shape") and len(getattr(sc_k, "shape", ())) == 1:
+            raise RuntimeError("sesrq calibration: define.WEIGHT_PER_CHANNEL is an inference-time option of this package (no reference counterpart); "
+                               "calibrate the activation domains with the reference's per-tensor weights (test.py), then switch it on")
+        quantized.append((wq.astype(np.int8), float(sc_k)))
         biases.append(np.asarray(pb.kwargs["bias"], dtype=np.float32))
     ps = 1
     for n in gm.graph.nodes:

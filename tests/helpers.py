@@ -12,7 +12,8 @@ from sesrq.bundle import Bundle, LayerParams
 
 
 def bundle_from_oracle(net: O.Net) -> Bundle:
-    return Bundle(layers=[LayerParams(wq=l.wq, add_const=l.add_const, M=l.M, n=l.n, relu=l.relu) for l in net.layers],
+    return Bundle(layers=[LayerParams(wq=l.wq, add_const=l.add_const, M=l.M, n=l.n, relu=l.relu, M_oc=getattr(l, 'M_oc', None),
+                                      n_oc=getattr(l, 'n_oc', None)) for l in net.layers],
                   scale=list(net.scale), zero=list(net.zero), M_res=net.M_res, n_res=net.n_res,
                   pixel_shuffle=net.pixel_shuffle, pe_num=net.pe, pe_acc_bits=net.acc_bits, pe_add_bits=net.add_bits,
                   name=net.name)

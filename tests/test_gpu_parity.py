@@ -985,3 +985,51 @@ def test_overflow_counters_mirror_the_reference_prints():
                 assert ovf[k, 0] == int((raw > 131071).sum()) and ovf[k, 1] == int((raw < -131072).sum())
         assert bool(ovf.any()) == expect, (tag, ovf)
         _cmp("q_out with the counter tap", res["q_out"], st["q_out"])
+
+
+def test_per_channel_weight_scales_vs_oracle():
+    """Round 5: per-output-channel requant constants (sesrq_layer_desc.M_oc / n_oc) -- NOT in the reference, PARITY
+    UNPINNED: HIP against the numpy oracle's definition only.  Nets derived per channel from the reference's float weights (golden
+    params) and the reference's calibrated activation domains; a per-channel layer runs on the dot4 kernels (engine name says so), its
+    per-tensor neighbours keep their MFMA kernels; the per-tensor bundle of the same weights is a different result (the option is live)."""
+    from conftest import GOLDEN, load_fixture
+    for case, ps in (("sesr_x4", 4), ("nrdm_3", 1), ("sesr_x2_rand", 2), ("sesr_x2_rand_nat", 2)):
+        p, pm = load_fixture(os.path.join(GOLDEN, f"{case}.params.npz"))
+        Wf, bf = [p[f"Wf{k}"] for k in range(5)], [p[f"bf{k}"] for k in range(5)]
+        net = O.derive_net(Wf, bf, pm["scale"], pm["zero"], ps, per_channel=True)
+        e = sesrq.Engine(bundle_from_oracle(net), _dev())
+        assert all(n.startswith("dot4-") and n.endswith("-perchannel") for n in e.layer_engines()), e.layer_engines()
+        cin = Wf[0].shape[1]
+        for (N, H, W) in ((1, 24, 40), (2, 9, 33), (1, 1, 1)):
+            x = rand_frame((N, cin, H, W), 7 * H + W)
+            want = O.forward(net, x, keep=True)
+            q, y = e.forward(torch.from_numpy(x).to(_dev()))
+            _cmp(f"{case} per-channel {N}x{H}x{W} q", q, want["q_out"])
+            _cmp(f"{case} per-channel {N}x{H}x{W} y", y, want["y"])
+        res = e.forward_debug(torch.from_numpy(x).to(_dev()), pe=True, special=True)      # the taps too (N == 1 case left in x)
+        for k in range(5):
+            _cmp(f"input{k}", res[f"input{k}"], want[f"input{k}"])
+            _cmp(f"pe_add{k}", res[f"pe_add{k}"], want[f"pe_add{k}"])
+        _cmp("shortcut", res["shortcut"], want["shortcut"])
+        # mixed: only the middle hidden layer per channel -> that layer on dot4, no fused trio, the others on their MFMA kernels
+        tens = O.derive_net(Wf, bf, pm["scale"], pm["zero"], ps)
+        mixed = O.Net(**{**tens.__dict__, "layers": [net.layers[k] if k == 2 else tens.layers[k] for k in range(5)]})
+        em = sesrq.Engine(bundle_from_oracle(mixed), _dev())
+        names = em.layer_engines()
+        assert names[2].endswith("-perchannel") and all(n.startswith("mfma-") for i, n in enumerate(names) if i != 2), names
+        x = rand_frame((1, cin, 31, 70), 11)
+        wm = O.forward(mixed, x)
+        qm, ym = em.forward(torch.from_numpy(x).to(_dev()))
+        _cmp(f"{case} mixed q", qm, wm["q_out"])
+        _cmp(f"{case} mixed y", ym, wm["y"])
+        qt, _ = sesrq.Engine(bundle_from_oracle(tens), _dev()).forward(torch.from_numpy(x).to(_dev()))
+        assert not torch.equal(qt, qm), "per-channel constants change the result: the option is live"
+    # grouping needs the MFMA first / last layers: refused for a per-channel net, with the reason
+    import ctypes as C
+    ws = e.workspace(2, 8, 8, 3)
+    xs = torch.zeros((1, cin, 8, 8), device=_dev())
+    out = torch.zeros(e.out_shape(1, 8, 8), dtype=torch.int8, device=_dev())
+    io = (_lib.FrameIO * 2)(_lib.FrameIO(xs.data_ptr(), out.data_ptr(), None), _lib.FrameIO(xs.data_ptr(), out.data_ptr(), None))
+    rc = _lib.lib().sesrq_forward_many(e._h, io, 2, _lib.F32, 1, 8, 8, (C.c_void_p * 1)(ws.data_ptr()), ws.numel(),
+                                       (C.c_void_p * 1)(torch.cuda.current_stream().cuda_stream), 1, 2)
+    assert rc != 0 and "MFMA first- and last-layer kernels" in _lib.last_error()

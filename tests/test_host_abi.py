@@ -146,5 +146,40 @@ def test_instance_registry_lists_every_kernel_family():
     for f in ("conv_dot4_kernel", "mfma_f5_kernel_w4", "mfma_f5_kernel", "mfma_h3_kernel", "mfma_h5_kernel", "mfma_h5p_kernel", "mfma_trio_kernel",
               "unpack_nhwc16_kernel", "verify_fastdiv_kernel", "calib_conv_kernel", "calib_minmax_kernel", "calib_hist_kernel", "calib_fakequant_kernel"):
         assert fam.get(f, 0) >= 1, (f, fam)
-    assert fam["mfma_trio_kernel"] == 9 and "mfma_trio_kernel<1, 15>" in inst and "mfma_h5_kernel<1, 2, 22, 3>" in inst
+    assert fam["mfma_trio_kernel"] == 9 and "mfma_trio_kernel<1, 15>" in inst and "mfma_h5_kernel<1, 2, 22, 3, false>" in inst      # what bench.py times
     assert all(v == 0 for k, v in inst.items() if k.startswith("mfma_")), "nothing has been launched in a CPU session"
+
+
+def test_per_channel_weight_scales_host_side():
+    """Round 5: one weight scale per OUTPUT channel as a bundle option -- NOT in the reference (its quantiser is per
+    tensor, quan_func.py:58-71; BASELINE's north star names per-channel weights): PARITY UNPINNED.  Host side: the library's per-channel
+    quantiser and the derived per-channel requant constants equal the numpy oracle's definition; a bundle keeps them through save / load;
+    the per-tensor derivation is untouched (no M_oc)."""
+    p, pm = load_fixture(os.path.join(GOLDEN, "sesr_x2_rand.params.npz"))
+    Wf = [p[f"Wf{k}"] for k in range(5)]
+    bf = [p[f"bf{k}"] for k in range(5)]
+    for w in Wf:
+        q, s = sesrq.quantize_weight_per_channel(w)
+        oq, os_ = O.quantize_weight_per_channel(w)
+        np.testing.assert_array_equal(q, oq)
+        assert list(s) == list(os_)
+        assert all(np.abs(q[o].astype(np.int32)).max() >= 127 for o in range(q.shape[0])), "every channel uses its full int8 range"
+    b = sesrq.derive_bundle(Wf, bf, pm["scale"], pm["zero"], 2, per_channel=True)
+    net = O.derive_net(Wf, bf, pm["scale"], pm["zero"], 2, per_channel=True)
+    for lb, ln in zip(b.layers, net.layers):
+        np.testing.assert_array_equal(lb.wq, ln.wq)
+        np.testing.assert_array_equal(lb.add_const, ln.add_const)
+        assert list(lb.M_oc) == list(ln.M_oc) and list(lb.n_oc) == list(ln.n_oc)
+        assert len(set(zip(lb.M_oc.tolist(), lb.n_oc.tolist()))) > 1, "the channels really differ"
+    assert (b.M_res, b.n_res) == (net.M_res, net.n_res)
+    import tempfile
+    with tempfile.TemporaryDirectory() as d:
+        b.save(os.path.join(d, "pc.npz"))
+        b2 = sesrq.Bundle.load(os.path.join(d, "pc.npz"))
+    assert all(list(x.M_oc) == list(y.M_oc) and list(x.n_oc) == list(y.n_oc) for x, y in zip(b.layers, b2.layers))
+    bt = sesrq.derive_bundle(Wf, bf, pm["scale"], pm["zero"], 2)
+    assert all(l.M_oc is None and l.n_oc is None for l in bt.layers)
+    with pytest.raises(ValueError, match="output channel 1"):
+        w0 = Wf[1].copy()
+        w0[1] = 0
+        sesrq.quantize_weight_per_channel(w0)
