@@ -253,6 +253,7 @@ def main():
             shp_ = e.out_shape(n_, h_, w_)
             h_, w_ = shp_[2], shp_[3]
         op_ws = [[e.workspace(*dims[j], sl) for j, e in enumerate(engines)] for sl in range(NS)]
+        op_into, op_streams = torch.ops.sesrq.forward_into.default, [st.cuda_stream for st in streams]
     graphs = {}
     if args.graph and B > 0:       # one graph per (stream slot, pool frame): the input pointer is part of a graph
         for slot in range(NS):
@@ -267,11 +268,10 @@ def main():
                 graphs[(i % NS, i % POOL)].replay()
         elif B > 0 and args.submit == "op":
             sl = i % NS
-            with torch.cuda.stream(streams[sl]):
-                cur = pool[i % POOL]
-                for j, eid in enumerate(op_ids):
-                    torch.ops.sesrq.forward_into(cur, eid, outs[sl][j], None, op_ws[sl][j])
-                    cur = outs[sl][j]
+            cur = pool[i % POOL]
+            for j, eid in enumerate(op_ids):      # the stream travels as a raw handle: no Python stream context per step
+                op_into(cur, eid, outs[sl][j], None, op_ws[sl][j], op_streams[sl])
+                cur = outs[sl][j]
         elif B > 0:
             forward_chain(pool[i % POOL], i % NS, streams[i % NS])
 

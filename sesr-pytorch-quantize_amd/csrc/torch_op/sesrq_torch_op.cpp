@@ -3,7 +3,8 @@
 // stream".  Replaces the reference's `gfake = model(inps)` (sim.py:205) as ONE operator of the lowered fx graph.  torch is plumbing here:
 // output / workspace memory from the caching allocator, the current HIP stream, the dispatcher; the work is sesrq_forward (libsesrq.so).
 //   (q, y) = torch.ops.sesrq.forward(x, engine_id)          q: int8 input.L after PixelShuffle, y: fp32 -- what the reference returns
-//   torch.ops.sesrq.forward_into(x, engine_id, out_q, out_f, workspace)   caller-owned buffers (either output may be None): no allocation
+//   torch.ops.sesrq.forward_into(x, engine_id, out_q, out_f, workspace, stream=0)   caller-owned buffers (either output may be None): no
+//                                                             allocation; stream: a raw hipStream_t as an int, 0 = torch's current stream
 // engine_id: an operator schema cannot carry a pointer, so the immutable device net travels as an integer registered through
 // sesrq_torch_register (sesrq/torch_op.py calls it over ctypes when an Engine is registered, and sesrq_torch_unregister when it closes).
 #include <ATen/ATen.h>
@@ -42,8 +43,9 @@ Geometry geometry(const at::Tensor &x, const Entry &e) {
     return {x.scalar_type() == at::kFloat ? SESRQ_F32 : SESRQ_I8, x.size(0), x.size(2), x.size(3), e.cout / (e.r * e.r), x.size(2) * e.r, x.size(3) * e.r};
 }
 
-void run(const sesrq_net *net, const at::Tensor &x, const Geometry &g, void *q, void *y, const at::Tensor &ws) {
-    const hipStream_t st = c10::hip::getCurrentHIPStream(x.device().index()).stream();
+// stream: a raw hipStream_t handed over as an integer (torch.cuda.Stream.cuda_stream), or 0 = torch's current stream of the input's device
+void run(const sesrq_net *net, const at::Tensor &x, const Geometry &g, void *q, void *y, const at::Tensor &ws, int64_t stream = 0) {
+    const hipStream_t st = stream ? reinterpret_cast<hipStream_t>(stream) : c10::hip::getCurrentHIPStream(x.device().index()).stream();
     const int rc = sesrq_forward(net, x.data_ptr(), g.dt, q, y, (int)g.N, (int)g.H, (int)g.W, ws.data_ptr(), (size_t)ws.numel(), (void *)st);
     TORCH_CHECK(rc == 0, "sesrq: ", sesrq_last_error());
 }
@@ -68,7 +70,7 @@ std::tuple<at::Tensor, at::Tensor> forward_meta(const at::Tensor &x, int64_t id)
 }
 
 void forward_into_hip(const at::Tensor &x, int64_t id, const c10::optional<at::Tensor> &out_q, const c10::optional<at::Tensor> &out_f,
-                      const at::Tensor &workspace) {
+                      const at::Tensor &workspace, int64_t stream) {
     const Entry en = entry_of(id);
     const sesrq_net *net = net_of(en);
     const Geometry g = geometry(x, en);
@@ -82,13 +84,13 @@ void forward_into_hip(const at::Tensor &x, int64_t id, const c10::optional<at::T
                               "forward_into: outputs must be contiguous (N, C, H*r, W*r) tensors on the input's device, int8 / float32");
         }
     const c10::DeviceGuard guard(x.device());
-    run(net, x, g, out_q.has_value() ? out_q->data_ptr() : nullptr, out_f.has_value() ? out_f->data_ptr() : nullptr, workspace);
+    run(net, x, g, out_q.has_value() ? out_q->data_ptr() : nullptr, out_f.has_value() ? out_f->data_ptr() : nullptr, workspace, stream);
 }
 }  // namespace
 
 TORCH_LIBRARY(sesrq, m) {
     m.def("forward(Tensor x, int engine_id) -> (Tensor, Tensor)");
-    m.def("forward_into(Tensor x, int engine_id, Tensor(a!)? out_q, Tensor(b!)? out_f, Tensor(c!) workspace) -> ()");
+    m.def("forward_into(Tensor x, int engine_id, Tensor(a!)? out_q, Tensor(b!)? out_f, Tensor(c!) workspace, int stream=0) -> ()");
 }
 TORCH_LIBRARY_IMPL(sesrq, CUDA, m) {      // HIP tensors dispatch on the CUDA key in PyTorch-ROCm
     m.impl("forward", &forward_hip);

@@ -385,7 +385,7 @@ def test_registered_torch_op_schema_and_fake_kernel():
     eid = torch_op.register_engine(eng)
     schema = str(torch.ops.sesrq.forward.default._schema)
     assert schema in ("sesrq::forward(Tensor x, int engine_id) -> (Tensor, Tensor)", "sesrq::forward(Tensor x, SymInt engine_id) -> (Tensor, Tensor)"), schema
-    assert "forward_into(Tensor x, int engine_id, Tensor(a!)? out_q, Tensor(b!)? out_f, Tensor(c!) workspace) -> ()" in str(torch.ops.sesrq.forward_into.default._schema)
+    assert "forward_into(Tensor x, int engine_id, Tensor(a!)? out_q, Tensor(b!)? out_f, Tensor(c!) workspace, int stream=0) -> ()" in str(torch.ops.sesrq.forward_into.default._schema)
     # the kernels are C++ functions, not Python callables: nothing of the op is registered from Python
     assert torch._C._dispatch_has_kernel_for_dispatch_key("sesrq::forward", "CUDA") and torch._C._dispatch_has_kernel_for_dispatch_key("sesrq::forward", "Meta")
     assert not torch._C._dispatch_has_kernel_for_dispatch_key("sesrq::forward", "CPU")

@@ -3,7 +3,7 @@
 #   gpurun --timeout 1100 -- 'bash tools/profile_round.sh r02'
 # rocprofv3 is given the program itself after `--` (python3 bench.py ...), PMC passes are separate runs without any trace
 # domain but --kernel-trace (gpurun refuses other combinations); FETCH_SIZE and WRITE_SIZE need a pass each (TCC slots).
-R=${1:-r04}
+R=${1:-r05}
 O=gpurun_out/$R
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
