@@ -50,6 +50,7 @@ struct LastStore {
     int vo[4];            // element offset of slot i inside image n_img (out of range if invalid)
     int va[4];            // anchor add: element offset of the slot's input pixel inside frame n_img (channel plane + column)
     const float *anc;
+    __amdgpu_buffer_rsrc_t ra;      // OUTF == 2: the image's fp32 input frame (the x2 anchor), one descriptor over its Cin planes
     int r, row_elems;     // PixelShuffle factor, r * Wo
     // lane_row: the lane's output row relative to the row passed to store() (pe-split kernel: lane group = row)
     // NV: real accumulator rows per lane group (last_slot_oc, sesrq_common.h); slot i >= NV of a lane is padding
@@ -73,6 +74,15 @@ struct LastStore {
             va[i] = (o < a.oc && gx < a.W) ? c * a.H * a.W + gx + lane_row * a.W : 0;
         }
         anc = a.anchor ? (a.ft.n ? (const float *)a.ft.in[n_img] : a.anchor + (size_t)n_img * cout * a.H * a.W) : nullptr;
+        ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(anc), 0, anc ? (int)((size_t)cout * a.H * a.W * 4) : 0, 0x00020000);
+    }
+    // OUTF == 2 (the x2 anchor add, test.py:148-155): the two input pixels this lane's three values of row gy add -- slots 0 / 1 share one
+    // (channel slot/4, same pixel: the pair is two sub-pixels of it), slot 2 the other.  Issued BEFORE the row's MFMA chain; a row below the
+    // frame reads out of range = 0.0f (its stores are dropped anyway).
+    __device__ __forceinline__ void fetch_anchor(const ConvArgs &a, int gy, float &x01, float &x2) const {
+        const int so = __builtin_amdgcn_readfirstlane(gy * a.W * 4);
+        x01 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ra, va[0] * 4, so, 0));
+        x2 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ra, va[2] * 4, so, 0));
     }
     // the shuffle factor is a constant in each branch: the slot decode costs shifts, not integer divisions
     // FAST = 2 / 4: the kernel instance is built for that shuffle factor (no switch, no dead arms in the prologue)
@@ -97,11 +107,14 @@ struct LastStore {
     // f32(scale_L) (quan_func.py:594) -- with the same run structure as the int8 flavours: one 8-byte store per 2-value run, one 16-byte
     // store per 4-value run (the every-output-kind path issues one dword store per value behind output-kind branches: 66 us per 1080p
     // frame, 1.5 TB/s).  No anchor add here (that keeps the general path).
-    template <bool BIASED, int FASTD = 0, int NV = 4, bool OUTF = false>
-    __device__ __forceinline__ void store(const int s[4], const ConvArgs &a, int gy, float zlo, bool row_ok = true) const {
+    // OUTF == 2: ... plus the x2 anchor add, y + x (one fp32 add per value; x01 / x2 from fetch_anchor): the pair map only (3 -> 12 channels,
+    // PixelShuffle 2 -- the reference's one anchor topology, models/sesr_arch.py:171-205); other shapes keep the general path
+    template <bool BIASED, int FASTD = 0, int NV = 4, int OUTF = 0>
+    __device__ __forceinline__ void store(const int s[4], const ConvArgs &a, int gy, float zlo, bool row_ok = true, float x01 = 0.f, float x2 = 0.f) const {
         constexpr int FAST = FASTD % 10;
         static_assert(!OUTF || FAST != 0, "fp32-only store: FAST flavours");
-        if constexpr (OUTF) {
+        static_assert(OUTF != 2 || (NV == 3 && FAST == 2), "anchor flavour: the pair map only");
+        if constexpr (OUTF != 0) {
             float yv[4] = {0.f, 0.f, 0.f, 0.f};
             const float sv = in_vgpr(a.s_out);
             if constexpr (FASTD >= 10) {
@@ -122,6 +135,7 @@ struct LastStore {
 #pragma unroll
                 for (int i = 0; i < NV; ++i) yv[i] = __fmul_rn(__fsub_rn(__builtin_rintf(med3(v[i], zlo, 127.f)), zo), sv);
             }
+            if constexpr (OUTF == 2) { yv[0] = __fadd_rn(yv[0], x01); yv[1] = __fadd_rn(yv[1], x01); yv[2] = __fadd_rn(yv[2], x2); }
             const int so = __builtin_amdgcn_readfirstlane(row_ok ? gy * (FAST * FAST * a.W) * 4 : 0x7fff0000);
             typedef float v2fs __attribute__((ext_vector_type(2)));
             typedef float v4fs __attribute__((ext_vector_type(4)));
@@ -510,8 +524,8 @@ __global__ __launch_bounds__(256) void mfma_h3_kernel(const ConvArgs a) {
 // 4 waves per SIMD: round 3, same-box A/B at 1080p: 5 waves (96 VGPRs, a handful of spills outside the row loop, a fifth workgroup per
 // CU) ran the last layer 5 % SLOWER than 4 (29.3 vs 27.7 us) and the fused trio 13 % slower (47.1 vs 41.6 us).
 // NV (EPI_LAST only): real accumulator rows per lane group, 3 for up to 12 output channels (last_slot_oc, sesrq_common.h)
-// OUTF (EPI_LAST, FAST != 0): the fp32 frame instead of the int8 one (LastStore::store)
-template <int MODE, int EPI, int FAST = 0, int NV = 4, bool OUTF = false>
+// OUTF (EPI_LAST, FAST != 0): 1 = the fp32 frame instead of the int8 one, 2 = ... with the x2 anchor add (LastStore::store)
+template <int MODE, int EPI, int FAST = 0, int NV = 4, int OUTF = 0>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void mfma_h5_kernel(const ConvArgs a) {
     constexpr bool GENERAL = mode_general(MODE);
     constexpr int SW = MTW + 8;          // 2 + 64 + 2 halo, + over-read of the kx = 4..7 group
@@ -597,6 +611,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void m
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int y = y4 + r;
+                    float x01 = 0.f, x2 = 0.f;
+                    if constexpr (OUTF == 2) ls.fetch_anchor(a, y0 + y, x01, x2);
                     B[(y + 4) % 5] = ld_frag(tile + (y + 4) * SW + col);
                     const v4i C5 = ld_frag(tile + (y + g) * SW + colc);      // column 4: lane group g = kernel row g
                     const v4i C6 = ld_frag(tile + (y + 4) * SW + colc);      // tap (4,4)
@@ -621,7 +637,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void m
                     if constexpr (EPI == EPI_LAST) {
                         // a row below the frame is dropped by its offsets (FAST: the scalar one, else the lanes'), not by a
                         // branch: the four rows stay one basic block
-                        ls.template store<BIASED, FAST, NV, OUTF>(s4[r], a, y0 + y, zlo, y0 + y < a.H);
+                        ls.template store<BIASED, FAST, NV, OUTF>(s4[r], a, y0 + y, zlo, y0 + y < a.H, x01, x2);
                     }
                 }
                 if constexpr (EPI != EPI_LAST) emit_rows4<EPI, false, BIASED>(s4, a, io, y4, zlo);
@@ -641,6 +657,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void m
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {                            // tile rows par + 2t
                     const int gy = y0 + par + 2 * t;
+                    float x01 = 0.f, x2 = 0.f;
+                    if constexpr (OUTF == 2) { if (j == 0) ls.fetch_anchor(a, gy, x01, x2); else ls1.fetch_anchor(a, gy, x01, x2); }
                     const v4i zero = {0, 0, 0, 0};
                     v4i acc[4];
                     // a pair of row t + 1 is a pair of row t in another operand slot: hide the relation between the rows' addresses from the
@@ -664,8 +682,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void m
                     finish_sums<MODE, NV>(s4[t], acc, ac, a);
                     if constexpr (EPI == EPI_LAST) {
                         // a row below the frame is dropped by its offsets (FAST: the scalar one, else the lanes'), not by a branch
-                        if (j == 0) ls.template store<BIASED, FAST, NV, OUTF>(s4[t], a, gy, zlo, gy < a.H);
-                        else ls1.template store<BIASED, FAST, NV, OUTF>(s4[t], a, gy, zlo, gy < a.H);
+                        if (j == 0) ls.template store<BIASED, FAST, NV, OUTF>(s4[t], a, gy, zlo, gy < a.H, x01, x2);
+                        else ls1.template store<BIASED, FAST, NV, OUTF>(s4[t], a, gy, zlo, gy < a.H, x01, x2);
                     }
                 }
                 if constexpr (EPI != EPI_LAST) {
@@ -1155,10 +1173,15 @@ int launch_mfma(const LayerPlan &lp, const ConvArgs &a_in, int src, int epi, boo
             else if (epi == EPI_PRERES) SESRQ_BY_MODE(mfma_h5_kernel, EPI_PRERES);
             // (below) d1: the output requant as one fma -- proven for this layer's (M, n), zero point -128, biased sums, int8 output only
 
+            // fp32 frame + the x2 anchor add on the pair map (3 -> 12 channels, PixelShuffle 2): OUTF = 2; the one-fma forms do not care about the anchor
+            else if (!a.out_q && a.out_f && a.anchor && last_nv(a.oc) == 3 && last_pairmap(a.oc, a.ps) && a.ic == 16) {
+                const bool da = a.direct && mode != GEN_ANY && a.z_out == -128.f;
+                if (da && a.direct == 1) SESRQ_BY_MODE_B(mfma_h5_kernel, EPI_LAST, 12, 3, 2); else if (da && a.direct == 2) SESRQ_BY_MODE_B(mfma_h5_kernel, EPI_LAST, 22, 3, 2); else SESRQ_BY_MODE(mfma_h5_kernel, EPI_LAST, 2, 3, 2);
+            }
             // fp32 frame only (the reference's return type), no anchor: the OUTF flavours of the same FAST instances
-            else if (!a.out_q && a.out_f && !a.anchor && last_nv(a.oc) == 3 && last_pairmap(a.oc, a.ps)) { if (d1) SESRQ_BY_MODE_B(mfma_h5_kernel, EPI_LAST, 12, 3, true); else if (d2) SESRQ_BY_MODE_B(mfma_h5_kernel, EPI_LAST, 22, 3, true); else SESRQ_BY_MODE(mfma_h5_kernel, EPI_LAST, 2, 3, true); }
-            else if (!a.out_q && a.out_f && !a.anchor && last_nv(a.oc) == 4 && a.ps == 2) { if (d1) SESRQ_BY_MODE_B(mfma_h5_kernel, EPI_LAST, 12, 4, true); else if (d2) SESRQ_BY_MODE_B(mfma_h5_kernel, EPI_LAST, 22, 4, true); else SESRQ_BY_MODE(mfma_h5_kernel, EPI_LAST, 2, 4, true); }
-            else if (!a.out_q && a.out_f && !a.anchor && last_nv(a.oc) == 4 && a.ps == 4) { if (d1) SESRQ_BY_MODE_B(mfma_h5_kernel, EPI_LAST, 14, 4, true); else if (d2) SESRQ_BY_MODE_B(mfma_h5_kernel, EPI_LAST, 24, 4, true); else SESRQ_BY_MODE(mfma_h5_kernel, EPI_LAST, 4, 4, true); }
+            else if (!a.out_q && a.out_f && !a.anchor && last_nv(a.oc) == 3 && last_pairmap(a.oc, a.ps)) { if (d1) SESRQ_BY_MODE_B(mfma_h5_kernel, EPI_LAST, 12, 3, 1); else if (d2) SESRQ_BY_MODE_B(mfma_h5_kernel, EPI_LAST, 22, 3, 1); else SESRQ_BY_MODE(mfma_h5_kernel, EPI_LAST, 2, 3, 1); }
+            else if (!a.out_q && a.out_f && !a.anchor && last_nv(a.oc) == 4 && a.ps == 2) { if (d1) SESRQ_BY_MODE_B(mfma_h5_kernel, EPI_LAST, 12, 4, 1); else if (d2) SESRQ_BY_MODE_B(mfma_h5_kernel, EPI_LAST, 22, 4, 1); else SESRQ_BY_MODE(mfma_h5_kernel, EPI_LAST, 2, 4, 1); }
+            else if (!a.out_q && a.out_f && !a.anchor && last_nv(a.oc) == 4 && a.ps == 4) { if (d1) SESRQ_BY_MODE_B(mfma_h5_kernel, EPI_LAST, 14, 4, 1); else if (d2) SESRQ_BY_MODE_B(mfma_h5_kernel, EPI_LAST, 24, 4, 1); else SESRQ_BY_MODE(mfma_h5_kernel, EPI_LAST, 4, 4, 1); }
             else if (last_nv(a.oc) == 3) {       // up to 12 output channels: three real rows per lane group (must match pack_mfma_frags)
                 if (a.out_q && !a.out_f && last_pairmap(a.oc, a.ps)) { if (d1) SESRQ_BY_MODE_B(mfma_h5_kernel, EPI_LAST, 12, 3); else if (d2) SESRQ_BY_MODE_B(mfma_h5_kernel, EPI_LAST, 22, 3); else SESRQ_BY_MODE(mfma_h5_kernel, EPI_LAST, 2, 3); }
                 else SESRQ_BY_MODE(mfma_h5_kernel, EPI_LAST, 0, 3);

@@ -324,6 +324,49 @@ def test_last_layer_instances_vs_oracle():
             check_vs_oracle(f"5x5 everywhere cout={cout}", craft_net(370 + cout, 3, cout, 1, ks=(5, 5, 5, 5, 5), risky=risky), [dict(engine=_lib.ENGINE_DOT4)], int8_too=False)
 
 
+def test_anchor_add_instances():
+    """The x2 anchor add of the reference's eval loop (test.py:148-155: gfake + inps_x2) with the fp32 frame out: round 5's store flavour for
+    the reference's one anchor topology (3 -> 12 channels, PixelShuffle 2).  Tier A: the reference-made sum for the SESR-x2 crop
+    (tests/golden/sesr_x2_rand.anchor.npz) under every requant form and accumulate mode the options reach; tier B: crafted nets for the other
+    modes, expected = the oracle's frame + the nearest-upsampled input (one fp32 add)."""
+    fx, meta, net, x = fixture_case(os.path.join(ROOT, "tests", "golden", "sesr_x2_rand.crop.npz"))
+    an = np.load(os.path.join(ROOT, "tests", "golden", "sesr_x2_rand.anchor.npz"), allow_pickle=False)
+    xt = torch.from_numpy(x).to(dev())
+    b = bundle_from_oracle(net)
+    for kw in (dict(), dict(reduced_forms=RF_ALL & ~16), dict(reduced_forms=RF_ALL & ~16 & ~32), dict(force_general=True), dict(fuse_hidden=0),
+               dict(engine=_lib.ENGINE_DOT4)):
+        with Track(pinned=True):
+            e = sesrq.Engine(b, dev(), anchor_add=True, **kw)
+            for wq, wf in ((False, True), (True, True)):
+                q, y = e.forward(xt, want_q=wq, want_f=wf)
+                eq(f"anchor {kw} q={wq}", y, an["sum_crop"])
+                if wq:
+                    eq(f"anchor {kw} int8 frame unaffected", q, shuffle(fx["input5"], 2))
+    for name, risky in (("merged", None), ("hybrid", {4: ((1,), range(16))}), ("general", {4: ((0, 2), range(16))})):
+        for form in (1, 2, None):
+            netc = craft_net(500 + len(name), 3, 12, 2, risky=risky, forms={4: form} if form else None)
+            for kw in (dict(), dict(reduced_forms=RF_ALL & ~16), dict(reduced_forms=RF_ALL & ~16 & ~32)):
+                e = sesrq.Engine(bundle_from_oracle(netc), dev(), anchor_add=True, **kw)
+                for (N, H, W) in ((1, 21, 70), (2, 9, 33)):
+                    xc = rand_frame((N, 3, H, W), 31 * H + W)
+                    want = O.forward(netc, xc)
+                    ya = (want["y"] + np.repeat(np.repeat(xc, 2, axis=2), 2, axis=3)).astype(np.float32)
+                    with Track(pinned=False):
+                        _, y = e.forward(torch.from_numpy(xc).to(dev()), want_q=False, want_f=True)
+                        eq(f"anchor craft {name} form {form} {kw} {N}x{H}x{W}", y, ya)
+    # ... and through the frame table of a grouped launch: every image adds ITS OWN input frame
+    e = sesrq.Engine(b, dev(), anchor_add=True)
+    xs = [torch.from_numpy(x * np.float32(0.5 + 0.1 * k)).to(dev()) for k in range(4)]
+    wants = [e.forward(t, want_q=False)[1].clone() for t in xs]
+    of = [torch.zeros_like(wants[0]) for _ in range(4)]
+    torch.cuda.synchronize()
+    with Track(pinned=False):
+        e.submission(xs, None, [torch.cuda.Stream(device=dev())], outs_f=of, group=4).enqueue(4)
+        torch.cuda.synchronize()
+        for k in range(4):
+            eq(f"anchor grouped frame {k}", of[k], wants[k].cpu().numpy())
+
+
 def test_trio_instances_vs_oracle():
     """Tier B: 8-conv nets (two fused trios: a plain one, EPI_MID, and the residual-merging one whose residual operand is NOT its input)
     under the five epilogue modes."""
