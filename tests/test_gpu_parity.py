@@ -1033,3 +1033,33 @@ def test_per_channel_weight_scales_vs_oracle():
     rc = _lib.lib().sesrq_forward_many(e._h, io, 2, _lib.F32, 1, 8, 8, (C.c_void_p * 1)(ws.data_ptr()), ws.numel(),
                                        (C.c_void_p * 1)(torch.cuda.current_stream().cuda_stream), 1, 2)
     assert rc != 0 and "MFMA first- and last-layer kernels" in _lib.last_error()
+
+
+def _big_cases():
+    from conftest import big_cases
+    return big_cases()
+
+
+@pytest.mark.parametrize("rec", [r for _, r in _big_cases()], ids=[r["case"] for _, r in _big_cases()])
+def test_baseline_size_natural_frames_match_the_reference(rec):
+    """Round 5: natural-ish frames at BASELINE sizes (SESR-x2 1080p -> 4K = config 2, nrdm_3 540p = config 3, SESR-x4 540p = config 4's frame)
+    that the REFERENCE itself ran through its sim path with a calibration it made on a natural frame (zero_0 < -128; the x2 net's 18-bit
+    PE clamp fires: it printed max_overflow).  The HIP path -- the production launch plan, each output kind -- must reproduce the SHA-256 of
+    the reference's int8 and fp32 results (tests/golden/*_nat.big.json; generator: make_golden.py)."""
+    from conftest import GOLDEN, big_input
+    fx, meta, net, _ = fixture_case(os.path.join(GOLDEN, rec["bundle"]))
+    assert meta["zero"][0] < -128
+    x = torch.from_numpy(big_input(rec)).to(_dev())
+    e = sesrq.Engine(bundle_from_oracle(net), _dev())
+    assert any("trio" in n for n in e.layer_engines())
+    q, y = e.forward(x)
+    assert list(q.shape) == rec["out_shape"]
+    assert _sha(q.cpu().numpy()) == rec["out_q_sha256"], "int8 frame differs from the reference's"
+    assert _sha(y.cpu().numpy()) == rec["out_f_sha256"], "fp32 frame differs from the reference's"
+    q1, _ = e.forward(x, want_f=False)
+    _, y1 = e.forward(x, want_q=False)
+    assert torch.equal(q1, q) and torch.equal(y1, y), "the int8-only / fp32-only kernel flavours give the same frames"
+    # the bench plan too: half-chip launches (wg_budget 512-like: two slots per CU)
+    e2 = sesrq.Engine(bundle_from_oracle(net), _dev(), wg_budget=2 * torch.cuda.get_device_properties(_dev()).multi_processor_count)
+    q2, _ = e2.forward(x, want_f=False)
+    assert torch.equal(q2, q)

@@ -354,6 +354,13 @@ def test_anchor_add_instances():
                     with Track(pinned=False):
                         _, y = e.forward(torch.from_numpy(xc).to(dev()), want_q=False, want_f=True)
                         eq(f"anchor craft {name} form {form} {kw} {N}x{H}x{W}", y, ya)
+    netw = craft_net(520, 3, 12, 2, bits=(17, 19), wide_all=True)      # run-time accumulator bounds (GEN_ANY) under the anchor flavour
+    e = sesrq.Engine(bundle_from_oracle(netw), dev(), anchor_add=True)
+    xc = rand_frame((1, 3, 21, 70), 77)
+    want = O.forward(netw, xc)
+    with Track(pinned=False):
+        _, y = e.forward(torch.from_numpy(xc).to(dev()), want_q=False, want_f=True)
+        eq("anchor craft 17/19 bits", y, (want["y"] + np.repeat(np.repeat(xc, 2, axis=2), 2, axis=3)).astype(np.float32))
     # ... and through the frame table of a grouped launch: every image adds ITS OWN input frame
     e = sesrq.Engine(b, dev(), anchor_add=True)
     xs = [torch.from_numpy(x * np.float32(0.5 + 0.1 * k)).to(dev()) for k in range(4)]

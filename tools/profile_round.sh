@@ -7,7 +7,7 @@ R=${1:-r05}
 O=gpurun_out/$R
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-B="--no-cpu-baseline --no-e2e"
+B="--no-cpu-baseline --no-e2e --no-boundary-legs"
 # 1. bench lines (the default command first: it is what the driver runs)
 python3 bench.py > $O/bench_default.json 2> $O/bench_default.err
 python3 bench.py --streams 1 $B > $O/bench_1stream.json 2>/dev/null
