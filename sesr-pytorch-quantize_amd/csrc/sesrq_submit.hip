@@ -198,6 +198,9 @@ void pool_shutdown() {
     SubmitPool *p = g_pool.exchange(nullptr);
     if (p && p->owner == getpid()) delete p;
 }
+// joins the threads when the library is unloaded or the process exits (a static object of the library rather than an atexit handler: the
+// handler would dangle after a dlclose)
+struct PoolReaper { ~PoolReaper() { pool_shutdown(); } } g_pool_reaper;
 SubmitPool &submit_pool() {
     SubmitPool *p = g_pool.load(std::memory_order_acquire);
     if (!p) {
@@ -205,7 +208,7 @@ SubmitPool &submit_pool() {
         p = g_pool.load(std::memory_order_acquire);
         if (!p) {
             static std::once_flag once;
-            std::call_once(once, [] { pthread_atfork(nullptr, nullptr, pool_atfork_child); atexit(pool_shutdown); });
+            std::call_once(once, [] { pthread_atfork(nullptr, nullptr, pool_atfork_child); });
             p = new SubmitPool();
             g_pool.store(p, std::memory_order_release);
         }

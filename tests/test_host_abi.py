@@ -146,7 +146,7 @@ def test_instance_registry_lists_every_kernel_family():
     for f in ("conv_dot4_kernel", "mfma_f5_kernel_w4", "mfma_f5_kernel", "mfma_h3_kernel", "mfma_h5_kernel", "mfma_h5p_kernel", "mfma_trio_kernel",
               "unpack_nhwc16_kernel", "verify_fastdiv_kernel", "calib_conv_kernel", "calib_minmax_kernel", "calib_hist_kernel", "calib_fakequant_kernel"):
         assert fam.get(f, 0) >= 1, (f, fam)
-    assert fam["mfma_trio_kernel"] == 9 and "mfma_trio_kernel<1, 15>" in inst and "mfma_h5_kernel<1, 2, 22, 3, false>" in inst      # what bench.py times
+    assert fam["mfma_trio_kernel"] == 9 and "mfma_trio_kernel<1, 15>" in inst and "mfma_h5_kernel<1, 2, 22, 3, 0>" in inst      # what bench.py times
     assert all(v == 0 for k, v in inst.items() if k.startswith("mfma_")), "nothing has been launched in a CPU session"
 
 
