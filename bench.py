@@ -310,6 +310,10 @@ def main():
                 many_checked += 1
                 many_bad += int(not torch.equal(q1, sub._keep[1][i]))
             counter[0] = nfirst      # the rotation goes on where this left it
+        elif args.submit == "op":      # the C++ operator is what is timed: its output is what is compared
+            step()
+            torch.cuda.synchronize()
+            got = outs[0][-1][0:1].cpu().numpy()
         else:
             got = forward_chain(pool[0], 0, torch.cuda.current_stream(dev))[0:1].cpu().numpy()
         torch.cuda.synchronize()
@@ -327,7 +331,7 @@ def main():
         diff = got.astype(np.int32) - want.astype(np.int32)
         maxdiff = int(np.abs(diff).max())
         path = ("HIP-graph replay" if graphs else (f"sesrq_forward_many ({NS} streams, {sub.group} frame(s) per launch sequence: the timed path)" if sub is not None
-                                                    else "sesrq_forward per step (the timed path)"))
+                                                    else ("torch.ops.sesrq.forward_into per step (the timed path)" if args.submit == "op" else "sesrq_forward per step (the timed path)")))
         parity = {"checked": f"full frame ({'x'.join(map(str, got.shape))}) of pool frame 0 through {path} vs C oracle", "max_abs_diff_int8": maxdiff,
                   "mismatches": int((diff != 0).sum()),
                   "psnr_db": "inf" if maxdiff == 0 else float(10 * np.log10(255.0 ** 2 / np.mean(diff.astype(np.float64) ** 2)))}

@@ -142,8 +142,10 @@ public:
         std::unique_lock<std::mutex> call(call_mu, std::try_to_lock);
         if (call.owns_lock()) grow(n);
     }
-    // jobs[0] runs on the caller's thread, jobs[1..] on the workers; false = the pool is busy (caller falls back to one thread)
-    bool run(std::vector<SubmitJob> &jobs) {
+    // jobs[0] runs on the caller's thread, jobs[1..] on the workers; false = the pool is busy (caller falls back to one thread).
+    // fatal (set on a stalled worker): the jobs have been moved to a leaked vector -- the worker still holds a pointer into it -- and the
+    // caller must return the error without looking at `jobs` again
+    bool run(std::vector<SubmitJob> &jobs, std::string *fatal = nullptr) {
         std::unique_lock<std::mutex> call(call_mu, std::try_to_lock);
         if (!call.owns_lock()) return false;
         grow(jobs.size() - 1);
@@ -174,9 +176,13 @@ public:
                     if (mine) { run_job(*mine); w->done.store(true, std::memory_order_release); break; }
                 }
                 if (waited > std::chrono::seconds(STALL_S)) {
-                    jobs[i].rc = 1; jobs[i].bad = jobs[i].next;
-                    jobs[i].err = "submission thread stalled for " + std::to_string(STALL_S) + " s with frames in its hands";
-                    break;      // `done` stays false: the worker is never handed another job (run() would wait on it again and fail again)
+                    // the worker owns &jobs[i] and may still write to it: the vector must outlive this call -> moved (element addresses are
+                    // kept by a vector move) into an object that is never freed.  `done` stays false: the worker gets no further job.
+                    const std::string msg = "submission thread of stream " + std::to_string(i) + " stalled for " + std::to_string(STALL_S) + " s with frames in its hands";
+                    if (fatal) *fatal = msg;
+                    new std::vector<SubmitJob>(std::move(jobs));
+                    jobs.clear();
+                    return true;
                 }
                 std::this_thread::yield();
             }
@@ -242,7 +248,10 @@ int sesrq_forward_many(const sesrq_net *net, const sesrq_frame_io *frames, int c
     const int nj = std::min(n_streams, std::max(count, 1));
     for (int s = 0; s < nj; ++s)
         jobs.push_back(SubmitJob{net, frames, count, s, n_streams, in_dtype, N, H, W, workspaces[s], workspace_bytes, streams[s], group, s});
-    if (!(pooled && submit_pool().run(jobs))) {      // one thread: the streams take turns, one launch sequence each
+    std::string fatal;
+    const bool ran = pooled && submit_pool().run(jobs, &fatal);
+    if (!fatal.empty()) { set_error("sesrq_forward_many: " + fatal); return 1; }
+    if (!ran) {      // one thread: the streams take turns, one launch sequence each
         for (bool any = true; any;) {
             any = false;
             for (auto &j : jobs) any |= job_step(j);
@@ -261,7 +270,9 @@ int sesrq_submit_selftest(int n_streams, int rounds) {
     for (int r = 0; r < rounds; ++r) {
         std::vector<SubmitJob> jobs((size_t)n_streams);
         for (auto &j : jobs) j.selftest = &ran;
-        if (!submit_pool().run(jobs)) { set_error("sesrq_submit_selftest: the pool is busy"); return -1; }
+        std::string fatal;
+        if (!submit_pool().run(jobs, &fatal)) { set_error("sesrq_submit_selftest: the pool is busy"); return -1; }
+        if (!fatal.empty()) { set_error("sesrq_submit_selftest: " + fatal); return -1; }
         for (auto &j : jobs)
             if (j.rc) { set_error("sesrq_submit_selftest: " + j.err); return -1; }
     }
