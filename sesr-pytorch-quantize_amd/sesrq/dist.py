@@ -94,8 +94,11 @@ def oversubscribed(local_world: int, cpus=None) -> bool:
 
 def pin_rank_cpus(local_rank: int, local_world: int):
     """Pin this process (and every thread it starts afterwards: torch's, the library's submission threads) to its slice of the node's CPUs.
-    One rank per GPU each spins on its own streams; without a pin, eight ranks' enqueue threads migrate over each other.  Returns the slice."""
+    One rank per GPU each spins on its own streams; without a pin, eight ranks' enqueue threads migrate over each other.  Returns the CPUs
+    the process may run on afterwards (its slice; the unchanged set where a slice would hold fewer than four CPUs)."""
     mine = rank_cpus(local_rank, local_world)
+    if len(mine) < 4:      # a rank runs up to four busy threads (three submission threads + the fence): a smaller slice would stack them; no pin
+        return sorted(os.sched_getaffinity(0))
     try:
         os.sched_setaffinity(0, mine)
     except OSError:
