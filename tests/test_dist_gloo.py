@@ -30,7 +30,9 @@ def _worker(rank, world, port, q):
     import sys
     import time
     os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-    from sesrq.dist import Group, run_timed, shard as sh
+    from sesrq.dist import Group, pin_rank_cpus, run_timed, shard as sh
+    allowed = sorted(os.sched_getaffinity(0))
+    cpus = pin_rank_cpus(rank, world)                 # bench.py's first act in a rank
     g = Group(backend="gloo")
     mine = sh(11, g.world, g.rank)
     # a "step" = this rank's frames through a stand-in per-frame function (the engine is the only thing stubbed:
@@ -45,7 +47,7 @@ def _worker(rank, world, port, q):
     synced = []
     res = run_timed(g, step, steps=3, warmup=2, repeats=2, sync=lambda: synced.append(len(log)), units_per_step=len(mine))
     elapsed = g.max_over_ranks(0.5 + rank)
-    q.put((rank, list(mine), elapsed, res, len(log), synced))
+    q.put((rank, list(mine), elapsed, res, len(log), synced, cpus, sorted(os.sched_getaffinity(0)), allowed))
     g.close()
 
 
@@ -62,7 +64,12 @@ def test_two_rank_gloo_fence_and_sharding():
         assert p.exitcode == 0
     assert res[0][1] + res[1][1] == list(range(11))          # uneven shards (6 + 5), every frame exactly once
     assert all(abs(r[2] - 1.5) < 1e-12 for r in res), "MAX over ranks"
-    for rank, mine, _, timed, nlog, synced in res:
+    # round 5: every rank lives on its own slice of the CPUs (live affinities, not just the arithmetic): disjoint and covering
+    allowed = res[0][8]
+    if len(allowed) >= 8:
+        assert all(r[6] == r[7] for r in res), "the affinity the kernel reports is the slice"
+        assert not set(res[0][7]) & set(res[1][7]) and sorted(res[0][7] + res[1][7]) == allowed, (res[0][7], res[1][7])
+    for rank, mine, _, timed, nlog, synced, *_aff in res:
         assert timed["units_per_step_total"] == 11, "sum over ranks of the frames per step"
         hs = timed["host_enqueue_sample_steps"]
         assert hs >= 16 and timed["host_enqueue_s_per_step"] >= 0.02 * 0.9
