@@ -52,6 +52,9 @@ CASES = {
     "sesr_x4_nat":      dict(mflag=5, ckpt="model_params/x4sesr.pth", inp="natural", qat=False, nat_seed=2024, big=(540, 960)),
     "nrdm_3_nat":       dict(mflag=3, ckpt="model_params/nrdm_3_raw_G.pth", inp="natural", qat=False, nat_seed=2025, big=(540, 960)),
     "sesr_x2_rand_nat": dict(mflag=6, ckpt=None, inp="natural", qat=False, seed=1234, nat_seed=2026, big=(1080, 1920)),
+    # ... and the QAT checkpoints BASELINE.json's configs name (config 0: sr_qat_G.pth, config 2: nrdm_3_qat_G.pth at 960x540)
+    "sesr_x4_qat_nat":  dict(mflag=5, ckpt="model_params/sr_qat_G.pth", inp="natural", qat=True, nat_seed=2027, big=(540, 960)),
+    "nrdm_3_qat_nat":   dict(mflag=3, ckpt="model_params/nrdm_3_qat_G.pth", inp="natural", qat=True, nat_seed=2028, big=(540, 960)),
 }
 CROP_H, CROP_W = 24, 40
 
