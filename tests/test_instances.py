@@ -401,8 +401,7 @@ def test_calibration_and_proof_kernels_run():
         torch.cuda.synchronize()
     # the load-time proof of the input quantiser's division form runs once per (scale_0, zero_0) of a process (cached): a domain no other
     # test of the session has used makes sesrq_create launch it here, and the forward that relies on the proof is checked against the oracle
-    import time
-    fresh = O.Net(**{**net.__dict__, "scale": [net.scale[0] * (1.0 + 1e-3 * (1 + time.time() % 1))] + list(net.scale[1:])})
+    fresh = O.Net(**{**net.__dict__, "scale": [net.scale[0] * (1.0 + 2.0 ** -10 + 2.0 ** -17)] + list(net.scale[1:])})      # used nowhere else
     with Track(pinned=False):
         e = sesrq.Engine(bundle_from_oracle(fresh), dev())
         assert e.fast_division_proven()
