@@ -21,6 +21,11 @@ Usage:  python tests/golden/make_golden.py            # all cases (spawns one pr
                                                                    # (SESR-x2 random-init net, 1x3x1080x1920, dump flags off) + SHA-256 of its
                                                                    # int8 / fp32 output -> reference_x2_1080p.json
         python tests/golden/make_golden.py --case anchor          # AnchorOp (sesr_arch.py:171-205) + the eval loop's x2 add (test.py:148-155)
+        python tests/golden/make_golden.py --case sesr_x4_nat     # round 5: a natural-ish frame (tests/golden/natural.py), CALIBRATED ON IT by the
+                                                                   # reference (zero_0 < -128 with its consistent scale): crop with every stage, 80x960
+                                                                   # SHAs, and a BASELINE-size frame through the reference's sim path (*.big.json)
+        python tests/golden/make_golden.py --case nrdm_3 --fuzz 30   # numpy oracle vs the reference on 30 random small frames, each calibrated
+                                                                   # by the reference; writes nothing (log: profiles/r05_oracle_vs_reference_fuzz.txt)
 """
 import argparse
 import hashlib
@@ -63,7 +68,7 @@ def sha(a: np.ndarray) -> str:
     return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
 
 
-def run_case(name: str, out_dir: str, time_1080p: bool = False) -> None:
+def run_case(name: str, out_dir: str, time_1080p: bool = False, fuzz: int = 0) -> None:
     cfg = CASES[name]
     sys.dont_write_bytecode = True
     sys.path.insert(0, REF)
@@ -130,9 +135,9 @@ def run_case(name: str, out_dir: str, time_1080p: bool = False) -> None:
         return model
 
     natural = cfg["inp"] == "natural"
+    sys.path.insert(0, HERE)
+    from natural import natural_frame, interesting_crop
     if natural:
-        sys.path.insert(0, HERE)
-        from natural import natural_frame, interesting_crop
         x_full = torch.from_numpy(natural_frame(1 if cfg["mflag"] == 5 else 3, 80, 960, cfg["nat_seed"]))
     else:
         x_full = torch.load(os.path.join(REF, cfg["inp"]), weights_only=True, map_location="cpu").float()
@@ -146,28 +151,34 @@ def run_case(name: str, out_dir: str, time_1080p: bool = False) -> None:
     bf = [c.bias.detach().numpy().copy() for c in convs]
 
     # ---------------- mode 0: calibration on the full random input (test.py semantics)
-    cal = splice(make(float_cls), 0)
-    with torch.no_grad():
-        y_cal = cal(x_full)
-    QMAX, QMIN = 127, -128
-    mins, maxs, scales, zeros = [], [], [], []
-    for i in range(6):
-        mx = torch.load(f"output_pt/input/input.{i}.max_val.pt")
-        mn = torch.load(f"output_pt/input/input.{i}.min_val.pt")
-        mins.append(mn); maxs.append(mx)
-        if i == 5:
-            mn = 0
-        s = (mx - mn) / (QMAX - QMIN)
-        z = QMIN - round(mn / s)
-        torch.save(s, f"output_pt/input/input.{i}.scale.pt")
-        torch.save(z, f"output_pt/input/input.{i}.zero.pt")
-        scales.append(float(s)); zeros.append(int(z))
+    def calibrate(x_cal):
+        import glob
+        for f in glob.glob("output_pt/input/input.*.m??_val.pt"):      # test.py:108-113 resets the running ranges before its loop
+            os.remove(f)
+        cal = splice(make(float_cls), 0)
+        with torch.no_grad():
+            y_c = cal(x_cal)
+        QMAX, QMIN = 127, -128
+        mins_, maxs_, scales_, zeros_ = [], [], [], []
+        for i in range(6):
+            mx = torch.load(f"output_pt/input/input.{i}.max_val.pt")
+            mn = torch.load(f"output_pt/input/input.{i}.min_val.pt")
+            mins_.append(mn); maxs_.append(mx)
+            if i == 5:
+                mn = 0
+            s = (mx - mn) / (QMAX - QMIN)
+            z = QMIN - round(mn / s)
+            torch.save(s, f"output_pt/input/input.{i}.scale.pt")
+            torch.save(z, f"output_pt/input/input.{i}.zero.pt")
+            scales_.append(float(s)); zeros_.append(int(z))
+        return y_c, mins_, maxs_, scales_, zeros_
+    y_cal, mins, maxs, scales, zeros = calibrate(x_full)
 
     # ---------------- mode 1 runs
     def ld(p):
         return torch.load(p)
 
-    def harvest(x, y, tag, full):
+    def harvest(x, y, tag, full, save=True):
         d = {}
         L = 5
         for k in range(L):
@@ -209,6 +220,8 @@ def run_case(name: str, out_dir: str, time_1080p: bool = False) -> None:
         d.update(keep)
         d["x"] = x.numpy().astype(np.float32) if not full else np.zeros(0, np.float32)
         d["meta"] = np.array(json.dumps(meta))
+        if not save:
+            return d
         np.savez_compressed(os.path.join(out_dir, f"{name}.{tag}.npz"), **d)
         print(f"[{name}.{tag}] M={M} n={nn_} res=({meta['M_res']},{meta['n_res']}) zero={zr}", flush=True)
 
@@ -236,6 +249,45 @@ def run_case(name: str, out_dir: str, time_1080p: bool = False) -> None:
                                     "bias_width": define.BIAS_BIT, "pe_num": define.PE, "exe_mode": 1}))
         with torch.no_grad():
             return m(x)
+
+    if fuzz:
+        # ORACLE vs REFERENCE, many small frames (round 5): every trial draws a frame (natural-ish or noise, random size and level), lets the
+        # REFERENCE calibrate on it (mode 0) and run its integer simulation (mode 1), and compares the numpy oracle with every tensor the
+        # reference wrote -- no fixture is kept, the log is (profiles/r05_oracle_vs_reference_fuzz.txt).
+        sys.path.insert(0, os.path.join(HERE, "..", ".."))
+        from oracle import sesrq_oracle as O
+        rng = np.random.default_rng(4242 + cfg["mflag"])
+        C = x_full.shape[1]
+        bad_total = 0
+        for t in range(fuzz):
+            h, w = int(rng.integers(7, 41)), int(rng.integers(9, 73))
+            kind = ("natural", "noise", "dim natural")[t % 3]
+            if kind == "noise":
+                xs = torch.rand((1, C, h, w), generator=torch.Generator().manual_seed(7000 + t)) * float(rng.uniform(0.3, 1.0)) + float(rng.uniform(0.0, 0.2))
+            else:
+                xs = torch.from_numpy(natural_frame(C, h, w, 6000 + t))
+                if kind == "dim natural":
+                    xs = xs * float(rng.uniform(0.2, 0.6))
+            xs = xs.float().contiguous()
+            _, _, _, sc_t, ze_t = calibrate(xs)
+            y = sim_run(xs)
+            d = harvest(xs, y, "fuzz", full=False, save=False)
+            net = O.net_from_fixture(d)
+            st = O.forward(net, d["x"], keep=True)
+            bad = 0
+            for k_, v_ in d.items():
+                if k_ in ("meta", "x") or k_.startswith(("Wq", "add_const")):
+                    continue
+                got = st["y" if k_ == "out" else k_]
+                bad += int((np.asarray(got).astype(v_.dtype) != v_).sum())
+            bad_total += bad
+            print(f"[fuzz {name} {t:3d}] {kind:11s} {h:2d}x{w:2d} zero={ze_t} mismatches={bad}", flush=True)
+        print(f"[fuzz {name}] {fuzz} reference runs, {bad_total} mismatching values in all dumped tensors", flush=True)
+        os.chdir(HERE)
+        shutil.rmtree(scratch, ignore_errors=True)
+        if bad_total:
+            raise SystemExit(1)
+        return
 
     # calibration record + float weights
     np.savez_compressed(
@@ -443,6 +495,8 @@ def run_anchor(out_dir: str) -> None:
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--case", default=None)
+    ap.add_argument("--fuzz", type=int, default=0, help="with --case <net>: N reference runs on random small frames (each calibrated by the reference) "
+                                                        "compared with the numpy oracle; nothing is written")
     args = ap.parse_args()
     os.makedirs(os.path.join(HERE, "..", "..", ".scratch"), exist_ok=True)
     if args.case == "tables":
@@ -452,7 +506,7 @@ def main():
     elif args.case == "anchor":
         run_anchor(HERE)
     elif args.case:
-        run_case(args.case, HERE)
+        run_case(args.case, HERE, fuzz=args.fuzz)
     else:
         # inputs (data files of the reference) as .npy
         import torch
