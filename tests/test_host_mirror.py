@@ -423,6 +423,54 @@ def test_lowered_one_op_graph_is_the_golden_output():
     np.testing.assert_array_equal(model(x).cpu().numpy(), fx["out"])
 
 
+@pytest.mark.gpu
+def test_cpp_operator_forward_into_on_reference_data():
+    """torch.ops.sesrq.forward / forward_into (the C++-registered operator, csrc/torch_op/sesrq_torch_op.cpp) on a reference-made crop:
+    allocating and caller-owned variants, each output kind, torch's current stream and a raw stream handle, a non-contiguous input, the
+    error paths -- and the extension library is really the loaded one."""
+    from sesrq import torch_op
+    from sesrq.bundle import Bundle
+    import sesrq
+    fx, meta = load_fixture(os.path.join(GOLDEN, "sesr_x2_rand_nat.crop.npz"))
+    dev = torch.device("cuda:0")
+    e = sesrq.Engine(Bundle.load(os.path.join(GOLDEN, "sesr_x2_rand_nat.crop.npz")), dev)
+    eid = torch_op.register_engine(e)
+    with open("/proc/self/maps") as f:
+        assert "sesrq_torch_op.so" in f.read(), "the C++ operator library is mapped into this process"
+    x = torch.from_numpy(fx["x"]).to(dev)
+    q5 = fx["input5"]
+    want_q = q5.reshape(1, 3, 2, 2, q5.shape[2], q5.shape[3]).transpose(0, 1, 4, 2, 5, 3).reshape(1, 3, 2 * q5.shape[2], 2 * q5.shape[3])
+    q, y = torch.ops.sesrq.forward(x, eid)
+    np.testing.assert_array_equal(q.cpu().numpy(), want_q)
+    np.testing.assert_array_equal(y.cpu().numpy(), fx["out"])
+    xnc = x.transpose(2, 3).contiguous().transpose(2, 3)
+    assert not xnc.is_contiguous()
+    np.testing.assert_array_equal(torch.ops.sesrq.forward(xnc, eid)[1].cpu().numpy(), fx["out"])
+    q0 = torch.from_numpy(fx["input0"]).to(dev)                       # the int8 entry (the reference's input.0)
+    np.testing.assert_array_equal(torch.ops.sesrq.forward(q0, eid)[0].cpu().numpy(), want_q)
+    ws = e.workspace(1, x.shape[2], x.shape[3], 5)
+    side = torch.cuda.Stream(device=dev)
+    for oq, of, st in ((True, False, 0), (False, True, 0), (True, True, side.cuda_stream)):
+        bq = torch.zeros(want_q.shape, dtype=torch.int8, device=dev) if oq else None
+        bf = torch.zeros(want_q.shape, dtype=torch.float32, device=dev) if of else None
+        torch.cuda.synchronize()
+        torch.ops.sesrq.forward_into(x, eid, bq, bf, ws, st)
+        torch.cuda.synchronize()
+        if oq:
+            np.testing.assert_array_equal(bq.cpu().numpy(), want_q)
+        if of:
+            np.testing.assert_array_equal(bf.cpu().numpy(), fx["out"])
+    with pytest.raises(ValueError, match="both outputs are None"):
+        torch.ops.sesrq.forward_into(x, eid, None, None, ws, 0)
+    with pytest.raises(ValueError, match="outputs must be contiguous"):
+        torch.ops.sesrq.forward_into(x, eid, torch.zeros((1, 3, 4, 4), dtype=torch.int8, device=dev), None, ws, 0)
+    with pytest.raises(RuntimeError, match="workspace too small"):
+        torch.ops.sesrq.forward_into(x, eid, torch.zeros(want_q.shape, dtype=torch.int8, device=dev), None, ws[:1024], 0)
+    e.close()                                                          # the C++ side drops the handle with the engine
+    with pytest.raises(RuntimeError, match="not registered"):
+        torch.ops.sesrq.forward(x, eid)
+
+
 def test_entropy_range_properties():
     """The host half of the entropy (KL) calibration variant -- no reference counterpart, PARITY UNPINNED: properties only.
     A distribution without outliers keeps its whole range; rare far outliers are clipped away; a domain that starts at
