@@ -428,13 +428,17 @@ struct StageNHWC16 {
     {                                                                                               \
         st.store(BUF0, a, tid);                                                                     \
         __syncthreads();                                                                            \
+        STAMP(2)                                                                                    \
         for (int t = t_begin; t < t_end; ++t) {                                                     \
             const int y0 = t * (TILE_H);                                                            \
             const bool cur0 = ((t - t_begin) & 1) == 0;                                             \
             if (t + 1 < t_end) st.load(a, n_img, x0, y0 + (TILE_H), tid);                           \
             { const int4 *cur_tile = cur0 ? BUF0 : BUF1; COMPUTE(cur_tile) }                        \
+            STAMP(3 + 3 * (t - t_begin))                                                            \
             if (t + 1 < t_end) { if (cur0) st.store_next(BUF1, BUF0, a, tid); else st.store_next(BUF0, BUF1, a, tid); }  \
+            STAMP(4 + 3 * (t - t_begin))                                                            \
             __syncthreads();                                                                        \
+            STAMP(5 + 3 * (t - t_begin))                                                            \
         }                                                                                           \
     }
 
