@@ -35,6 +35,10 @@ POOL = 8                     # distinct resident input frames the steps rotate o
 WORKLOADS = {
     "sesr_x2_1080p": (["sesr_x2_rand.crop.npz"], 3, 1080, 1920, ("per_gpu", 1),
                       "SESR-x2 INT8 1080p->4K (3->12ch, PixelShuffle 2)"),                       # BASELINE config 2 (headline)
+    # the same net calibrated BY THE REFERENCE on a natural-ish frame (zero_0 = -169), natural-ish frames in the pool (tests/golden/natural.py);
+    # pool frame 0 is the very 1080p frame the reference itself ran (sesr_x2_rand_nat.big.json): the last layer's 18-bit PE clamp fires on it
+    "sesr_x2_1080p_nat": (["sesr_x2_rand_nat.crop.npz"], 3, 1080, 1920, ("per_gpu", 1),
+                          "SESR-x2 INT8 1080p->4K on natural-ish frames, reference-calibrated on a natural frame"),
     "nrdm_3_540p": (["nrdm_3_qat.crop.npz"], 3, 540, 960, ("per_gpu", 1),
                     "nrdm_3 INT8 (nrdm_3_qat_G.pth) 960x540 denoise+demosaic (3->3ch)"),          # config 3 (the QAT checkpoint it names)
     "sesr_x4_540p": (["sesr_x4.crop.npz"], 1, 540, 960, ("per_gpu", 1), "SESR-x4 INT8 540p->4K (1->16ch, PixelShuffle 4)"),
@@ -49,7 +53,7 @@ WORKLOADS = {
 # 1080p: 3 streams x 512 slots 14.5 k frames/s vs 2 streams x full chip 14.2 k; anything else: the round-2 plan.
 # The budget is counted in workgroup slots PER COMPUTE UNIT (2 = half of the four a CU holds for these kernels) and scaled by the device's
 # CU count at run time: 2 x 256 = 512 on an MI355X (not a constant of this chip).
-PLAN = {"sesr_x2_1080p": (3, 2), "nrdm_3_540p": (3, 2), "sesr_x4_540p": (3, 2), "nrdm6_sesrx2_540p": (3, 2)}      # (streams, slots per CU): same-box A/Bs, profiles/README.md
+PLAN = {"sesr_x2_1080p": (3, 2), "sesr_x2_1080p_nat": (3, 2), "nrdm_3_540p": (3, 2), "sesr_x4_540p": (3, 2), "nrdm6_sesrx2_540p": (3, 2)}      # (streams, slots per CU): same-box A/Bs, profiles/README.md
 PLAN_DEFAULT = (2, 0)
 GROUP = {"nrdm_3_540p": 8, "sesr_x4_540p": 8}      # frames per launch sequence in --submit many (profiles/README.md, round 4); 1 elsewhere
 
@@ -199,7 +203,14 @@ def main():
         total_frames_per_step = B * world
     NS = max(1, args.streams)
     g = torch.Generator().manual_seed(1 + rank)
-    pool = [torch.rand((max(B, 1), cin, H, W), generator=g, dtype=torch.float32).to(dev) for _ in range(POOL)]
+    if args.workload.endswith("_nat"):      # natural-ish frames; frame 0 of rank 0 = the frame the reference ran (its SHA is checked below)
+        sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+        from natural import natural_frame
+        big = json.load(open(os.path.join(ROOT, "tests", "golden", fixtures[0].replace(".crop.npz", ".big.json"))))
+        pool = [torch.from_numpy(np.concatenate([natural_frame(cin, H, W, big["nat_seed"] + 1000 * rank + 10 * j + b_) for b_ in range(max(B, 1))])).to(dev)
+                for j in range(POOL)]
+    else:
+        pool = [torch.rand((max(B, 1), cin, H, W), generator=g, dtype=torch.float32).to(dev) for _ in range(POOL)]
     streams = [torch.cuda.Stream(device=dev) for _ in range(NS)]
     # chain hand-off: every net but the last hands its int8 output (N, C, H', W') to the next one's int8 input
     shapes = []
@@ -340,8 +351,8 @@ def main():
             parity["mismatches"] += many_bad
         # headline workload: pool frame 0 of rank 0 is the very frame the REFERENCE itself was run on in the build container
         # (tests/golden/reference_x2_1080p.json): the whole int8 4K frame against the reference's own output, by SHA-256
-        rf = os.path.join(ROOT, "tests", "golden", "reference_x2_1080p.json")
-        if args.workload == "sesr_x2_1080p" and os.path.isfile(rf) and B == 1 and not ekw["engine"] == _lib.ENGINE_DOT4:
+        rf = os.path.join(ROOT, "tests", "golden", "sesr_x2_rand_nat.big.json" if args.workload.endswith("_nat") else "reference_x2_1080p.json")
+        if args.workload in ("sesr_x2_1080p", "sesr_x2_1080p_nat") and os.path.isfile(rf) and B == 1 and not ekw["engine"] == _lib.ENGINE_DOT4:
             import hashlib
             ref = json.load(open(rf))
             if hashlib.sha256(np.ascontiguousarray(xs).tobytes()).hexdigest() == ref["x_sha256"]:
@@ -488,8 +499,8 @@ def boundary_legs(torch, np, sesrq, bundle, ekw, dev, pool, streams, args, drain
     legs = [("fp32_out", False)]
     if bundle.in_channels * r * r == cout_last:
         legs.append(("fp32_out_anchor_add", True))
-    rf = os.path.join(ROOT, "tests", "golden", "reference_x2_1080p.json")
-    ref = json.load(open(rf)) if (args.workload == "sesr_x2_1080p" and os.path.isfile(rf)) else None
+    rf = os.path.join(ROOT, "tests", "golden", "sesr_x2_rand_nat.big.json" if args.workload.endswith("_nat") else "reference_x2_1080p.json")
+    ref = json.load(open(rf)) if (args.workload in ("sesr_x2_1080p", "sesr_x2_1080p_nat") and os.path.isfile(rf)) else None
     for name, anchor in legs:
         e = sesrq.Engine(bundle, dev, anchor_add=anchor, **ekw)
         shp = e.out_shape(B, H, W)
